@@ -1,0 +1,416 @@
+/*
+ * fhe_oracle.c -- CPU ORACLE (TEST INFRASTRUCTURE ONLY; see fhe_oracle.h for the pinning statement).
+ *
+ * Written from the behaviour of the reference, not from its text: 64-bit limbs with explicit
+ * carries via unsigned __int128 stand where the reference strings PTX add.cc/addc/madc together
+ * (kernels/ptx_bigint.cuh:34-117).
+ */
+#include "fhe_oracle.h"
+
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+typedef unsigned __int128 u128;
+
+/* ------------------------------------------------------------------------------------------ */
+/* 256-bit wrap-around add / sub; return carry / borrow out of limb 3 (the reference drops it). */
+static inline unsigned add256(uint64_t r[4], const uint64_t a[4], const uint64_t b[4]) {
+    u128 c = 0;
+    for (int i = 0; i < 4; i++) { c += (u128)a[i] + b[i]; r[i] = (uint64_t)c; c >>= 64; }
+    return (unsigned)c;
+}
+static inline unsigned sub256(uint64_t r[4], const uint64_t a[4], const uint64_t b[4]) {
+    unsigned borrow = 0;
+    for (int i = 0; i < 4; i++) {
+        u128 d = (u128)a[i] - b[i] - borrow;
+        r[i] = (uint64_t)d;
+        borrow = (unsigned)(d >> 64) & 1u;
+    }
+    return borrow;
+}
+
+/* include/bigint.cuh:27-48.  NOTE the borrow test: the reference does not look at the borrow
+ * flag, it compares the top limbs (`temp.limbs[3] > result.limbs[3]`, :45) -- SURVEY D15. */
+void orc_add_mod(orc_u256 *r, const orc_u256 *a, const orc_u256 *b, const orc_u256 *q) {
+    uint64_t s[4], t[4];
+    add256(s, a->limbs, b->limbs);                 /* carry out of limb 3 discarded (:32-35) */
+    sub256(t, s, q->limbs);                        /* (:39-42) */
+    int underflow = t[3] > s[3];                   /* (:45) */
+    memcpy(r->limbs, underflow ? s : t, 32);
+}
+
+/* include/bigint.cuh:50-73 ; borrow detected as result.limbs[3] > a.limbs[3] (:61). */
+void orc_sub_mod(orc_u256 *r, const orc_u256 *a, const orc_u256 *b, const orc_u256 *q) {
+    uint64_t d[4], t[4];
+    sub256(d, a->limbs, b->limbs);
+    int borrow = d[3] > a->limbs[3];
+    if (borrow) { add256(t, d, q->limbs); memcpy(r->limbs, t, 32); }
+    else memcpy(r->limbs, d, 32);
+}
+
+/* include/bigint.cuh:76-140 : separated-operand-scanning Montgomery, R = 2^256.
+ * Product rows (:83-98), four reduction rounds m = t[i]*inv0 (:100-122) with the ripple stopping at
+ * limb 7 (carry out of the 512-bit accumulator is lost), result = upper half (:125-129), one
+ * conditional subtraction with the top-limb borrow test (:131-139). */
+void orc_mont_mul(orc_u256 *r, const orc_u256 *a, const orc_u256 *b, const orc_u256 *q, uint64_t inv0) {
+    uint64_t t[8] = {0};
+    for (int i = 0; i < 4; i++) {
+        uint64_t carry = 0;
+        for (int j = 0; j < 4; j++) {
+            u128 acc = (u128)a->limbs[i] * b->limbs[j] + carry + t[i + j];
+            t[i + j] = (uint64_t)acc;
+            carry = (uint64_t)(acc >> 64);
+        }
+        t[i + 4] = carry;
+    }
+    for (int i = 0; i < 4; i++) {
+        uint64_t m = t[i] * inv0;
+        uint64_t carry = 0;
+        for (int j = 0; j < 4; j++) {
+            u128 acc = (u128)m * q->limbs[j] + carry + t[i + j];
+            t[i + j] = (uint64_t)acc;
+            carry = (uint64_t)(acc >> 64);
+        }
+        for (int j = 4; j < 8 - i; j++) {
+            u128 acc = (u128)t[i + j] + carry;
+            t[i + j] = (uint64_t)acc;
+            carry = (uint64_t)(acc >> 64);
+        }
+    }
+    uint64_t u[4] = { t[4], t[5], t[6], t[7] }, d[4];
+    sub256(d, u, q->limbs);
+    int underflow = d[3] > u[3];
+    memcpy(r->limbs, underflow ? u : d, 32);
+}
+
+/* src/bigint.cu:23-40 : six Newton steps from x = 1 on the low limb, then negate. */
+uint64_t orc_mont_inverse(const orc_u256 *q) {
+    uint64_t inv = 1, n0 = q->limbs[0];
+    for (int i = 0; i < 6; i++) inv = inv * (2 - n0 * inv);
+    return (uint64_t)0 - inv;
+}
+
+/* include/ntt.cuh:147-155 : b is formed from the OLD a. */
+void orc_ct_butterfly(orc_u256 *a, orc_u256 *b, const orc_u256 *w, const orc_u256 *q, uint64_t inv0) {
+    orc_u256 t, na, nb;
+    orc_mont_mul(&t, b, w, q, inv0);
+    orc_sub_mod(&nb, a, &t, q);
+    orc_add_mod(&na, a, &t, q);
+    *a = na; *b = nb;
+}
+
+/* include/ntt.cuh:158-167 */
+void orc_gs_butterfly(orc_u256 *a, orc_u256 *b, const orc_u256 *w, const orc_u256 *q, uint64_t inv0) {
+    orc_u256 s, d, nb;
+    orc_add_mod(&s, a, b, q);
+    orc_sub_mod(&d, a, b, q);
+    orc_mont_mul(&nb, &d, w, q, inv0);
+    *a = s; *b = nb;
+}
+
+void orc_batch_add(orc_u256 *r, const orc_u256 *a, const orc_u256 *b, const orc_u256 *q, size_t count) {
+    for (size_t i = 0; i < count; i++) orc_add_mod(&r[i], &a[i], &b[i], q);
+}
+void orc_batch_sub(orc_u256 *r, const orc_u256 *a, const orc_u256 *b, const orc_u256 *q, size_t count) {
+    for (size_t i = 0; i < count; i++) orc_sub_mod(&r[i], &a[i], &b[i], q);
+}
+void orc_batch_mont(orc_u256 *r, const orc_u256 *a, const orc_u256 *b, const orc_u256 *q, uint64_t inv0, size_t count) {
+    for (size_t i = 0; i < count; i++) orc_mont_mul(&r[i], &a[i], &b[i], q, inv0);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* L1: the kernels as written.  Within one stage every thread touches a private (idx1, idx2)
+ * pair, so running the threads one after another between two barriers is equivalent. */
+static uint32_t ref_log_n(uint32_t n) { return (uint32_t)__builtin_popcount(n - 1) + 1; } /* ntt_kernels.cu:28 (sic: log2(n)+1) */
+
+void orc_ref_forward_kernel(orc_u256 *data, const orc_u256 *tw, const orc_u256 *q, uint64_t inv0, uint32_t n) {
+    uint32_t log_n = ref_log_n(n);
+    for (uint32_t stage = 0; stage < log_n; stage++) {
+        uint32_t m = 1u << stage, m2 = m << 1;
+        for (uint32_t tid = 0; tid < n; tid++) {
+            uint32_t k = tid / m, j = tid % m;
+            if ((uint64_t)k * m2 + j + m < n) {
+                uint32_t idx1 = k * m2 + j, idx2 = idx1 + m;
+                uint32_t tw_idx = j << (log_n - stage - 1);
+                orc_u256 u = data[idx1], v;
+                orc_mont_mul(&v, &data[idx2], &tw[tw_idx], q, inv0);
+                orc_add_mod(&data[idx1], &u, &v, q);
+                orc_sub_mod(&data[idx2], &u, &v, q);
+            }
+        }
+    }
+}
+
+void orc_ref_inverse_kernel(orc_u256 *data, const orc_u256 *itw, const orc_u256 *q, uint64_t inv0,
+                            const orc_u256 *n_inv, uint32_t n) {
+    uint32_t log_n = ref_log_n(n);
+    for (int stage = (int)log_n - 1; stage >= 0; stage--) {
+        uint32_t m = 1u << stage, m2 = m << 1;
+        for (uint32_t tid = 0; tid < n; tid++) {
+            uint32_t k = tid / m, j = tid % m;
+            if ((uint64_t)k * m2 + j + m < n) {
+                uint32_t idx1 = k * m2 + j, idx2 = idx1 + m;
+                uint32_t tw_idx = j << (log_n - (uint32_t)stage - 1);
+                orc_u256 u = data[idx1], v = data[idx2], d;
+                orc_add_mod(&data[idx1], &u, &v, q);
+                orc_sub_mod(&d, &u, &v, q);
+                orc_mont_mul(&data[idx2], &d, &itw[tw_idx], q, inv0);
+            }
+        }
+    }
+    for (uint32_t i = 0; i < n; i++) { orc_u256 x = data[i]; orc_mont_mul(&data[i], &x, n_inv, q, inv0); }
+}
+
+void orc_ref_pointwise_kernel(orc_u256 *r, const orc_u256 *a, const orc_u256 *b, const orc_u256 *q,
+                              uint64_t inv0, uint32_t n) {
+    for (uint32_t i = 0; i < n; i++) orc_mont_mul(&r[i], &a[i], &b[i], q, inv0);
+}
+
+void orc_ref_placeholder_table(orc_u256 *tw, uint32_t n) {
+    memset(tw, 0, (size_t)n * sizeof(orc_u256));
+    tw[0].limbs[0] = 1;                                      /* src/ntt.cu:86,93 */
+    for (uint32_t i = 1; i < n; i++) tw[i].limbs[0] = i;     /* src/ntt.cu:87-90,94-96 */
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* L2 plan: host maths built on the primitives above. */
+struct orc_plan {
+    uint32_t n, log_n;
+    orc_u256 q;
+    uint64_t inv0;
+    orc_u256 r1;        /* R mod q   (Montgomery form of 1) */
+    orc_u256 r2;        /* R^2 mod q */
+    orc_u256 psi;       /* plain */
+    orc_u256 n_inv_m;   /* n^-1 * R mod q */
+    orc_u256 *tw_m;     /* psi^bitrev(k) * R mod q, k in [0,n) */
+    orc_u256 *itw_m;    /* psi^-bitrev(k) * R mod q */
+};
+
+static int u256_is_zero(const orc_u256 *a) { return !(a->limbs[0] | a->limbs[1] | a->limbs[2] | a->limbs[3]); }
+static int u256_eq(const orc_u256 *a, const orc_u256 *b) { return memcmp(a, b, 32) == 0; }
+static orc_u256 u256_from(uint64_t v) { orc_u256 r = {{v, 0, 0, 0}}; return r; }
+static void u256_shr(orc_u256 *a, unsigned s) { /* 0 < s < 64 */
+    for (int i = 0; i < 4; i++) {
+        uint64_t hi = (i < 3) ? a->limbs[i + 1] : 0;
+        a->limbs[i] = (a->limbs[i] >> s) | (hi << (64 - s));
+    }
+}
+static uint32_t bitrev(uint32_t x, uint32_t bits) {
+    uint32_t r = 0;
+    for (uint32_t i = 0; i < bits; i++) { r = (r << 1) | (x & 1); x >>= 1; }
+    return r;
+}
+
+static void to_mont(const orc_plan *p, orc_u256 *r, const orc_u256 *a) { orc_mont_mul(r, a, &p->r2, &p->q, p->inv0); }
+static void from_mont(const orc_plan *p, orc_u256 *r, const orc_u256 *a) { orc_u256 one = u256_from(1); orc_mont_mul(r, a, &one, &p->q, p->inv0); }
+
+/* base^e, everything in Montgomery form except the exponent. */
+static void pow_mont(const orc_plan *p, orc_u256 *r, const orc_u256 *base_m, const orc_u256 *e) {
+    orc_u256 acc = p->r1;
+    for (int i = 255; i >= 0; i--) {
+        orc_u256 t; orc_mont_mul(&t, &acc, &acc, &p->q, p->inv0); acc = t;
+        if ((e->limbs[i / 64] >> (i % 64)) & 1) { orc_mont_mul(&t, &acc, base_m, &p->q, p->inv0); acc = t; }
+    }
+    *r = acc;
+}
+
+orc_plan *orc_plan_create(uint32_t n, const orc_u256 *q) {
+    if (n < 2 || (n & (n - 1)) || !(q->limbs[0] & 1) || (q->limbs[3] >> 63)) return NULL;
+    orc_plan *p = (orc_plan *)calloc(1, sizeof(*p));
+    if (!p) return NULL;
+    p->n = n; p->q = *q; p->inv0 = orc_mont_inverse(q);
+    while ((1u << p->log_n) < n) p->log_n++;
+
+    /* R mod q and R^2 mod q by 512 modular doublings of 1 (the reference sets r_squared = 1, src/bigint.cu:49). */
+    orc_u256 x = u256_from(1), one = x, t;
+    {   /* 1 mod q (q > 1 assumed) */
+        for (int i = 0; i < 512; i++) { orc_add_mod(&t, &x, &x, q); x = t; if (i == 255) p->r1 = x; }
+        p->r2 = x;
+    }
+    /* q = 1 mod 2n ? */
+    orc_u256 qm1; { orc_u256 z = u256_from(0); (void)z; qm1 = *q; qm1.limbs[0] -= 1; }
+    uint64_t two_n = 2ull * n;
+    if (qm1.limbs[0] & (two_n - 1)) { free(p); return NULL; }
+    orc_u256 e = qm1; u256_shr(&e, p->log_n + 1);            /* (q-1)/2n */
+    orc_u256 n_u = u256_from(n);
+    orc_u256 qm1_m; to_mont(p, &qm1_m, &qm1);                /* (q-1)*R mod q == -R */
+
+    /* psi search: first x = 2,3,... with (x^e)^n == -1. */
+    int found = 0;
+    for (uint64_t g = 2; g < 100000 && !found; g++) {
+        orc_u256 g_u = u256_from(g), g_m, c_m, c_n;
+        to_mont(p, &g_m, &g_u);
+        pow_mont(p, &c_m, &g_m, &e);
+        pow_mont(p, &c_n, &c_m, &n_u);
+        if (u256_eq(&c_n, &qm1_m)) { from_mont(p, &p->psi, &c_m); found = 1; }
+    }
+    if (!found) { free(p); return NULL; }
+
+    /* inverse of psi = psi^(2n-1); n^-1 = n^(q-2) (Fermat; q prime). */
+    orc_u256 psi_m, ipsi_m, ex;
+    to_mont(p, &psi_m, &p->psi);
+    ex = u256_from(two_n - 1);
+    pow_mont(p, &ipsi_m, &psi_m, &ex);
+    orc_u256 n_m; to_mont(p, &n_m, &n_u);
+    ex = *q; ex.limbs[0] -= 2;                               /* q odd > 2: no borrow */
+    pow_mont(p, &p->n_inv_m, &n_m, &ex);
+    /* sanity: n * n^-1 == 1 */
+    orc_mont_mul(&t, &n_m, &p->n_inv_m, q, p->inv0);
+    if (!u256_eq(&t, &p->r1)) { free(p); return NULL; }      /* q not prime */
+
+    p->tw_m = (orc_u256 *)malloc((size_t)n * sizeof(orc_u256));
+    p->itw_m = (orc_u256 *)malloc((size_t)n * sizeof(orc_u256));
+    if (!p->tw_m || !p->itw_m) { orc_plan_destroy(p); return NULL; }
+    /* natural powers, scattered to bit-reversed slots */
+    orc_u256 pw = p->r1, ipw = p->r1;
+    for (uint32_t k = 0; k < n; k++) {
+        uint32_t s = bitrev(k, p->log_n);
+        p->tw_m[s] = pw; p->itw_m[s] = ipw;
+        orc_mont_mul(&t, &pw, &psi_m, q, p->inv0); pw = t;
+        orc_mont_mul(&t, &ipw, &ipsi_m, q, p->inv0); ipw = t;
+    }
+    (void)one; (void)u256_is_zero;
+    return p;
+}
+
+void orc_plan_destroy(orc_plan *p) { if (!p) return; free(p->tw_m); free(p->itw_m); free(p); }
+void orc_plan_psi(const orc_plan *p, orc_u256 *psi) { *psi = p->psi; }
+uint64_t orc_plan_inv0(const orc_plan *p) { return p->inv0; }
+void orc_plan_twiddle(const orc_plan *p, uint32_t k, orc_u256 *w) { from_mont(p, w, &p->tw_m[k % p->n]); }
+
+/* Merged-twiddle Cooley-Tukey, natural in -> bit-reversed out.  Twiddles are in Montgomery form,
+ * data in plain form, so ct_butterfly's mont(b, w) is the exact plain product. */
+void orc_ntt_forward(const orc_plan *p, orc_u256 *x) {
+    uint32_t n = p->n, t = n;
+    for (uint32_t m = 1; m < n; m <<= 1) {
+        t >>= 1;
+        for (uint32_t i = 0; i < m; i++) {
+            uint32_t j1 = 2 * i * t;
+            const orc_u256 *w = &p->tw_m[m + i];
+            for (uint32_t j = j1; j < j1 + t; j++) orc_ct_butterfly(&x[j], &x[j + t], w, &p->q, p->inv0);
+        }
+    }
+}
+
+/* Gentleman-Sande, bit-reversed in -> natural out, then the n^-1 scaling. */
+void orc_ntt_inverse(const orc_plan *p, orc_u256 *x) {
+    uint32_t n = p->n, t = 1;
+    for (uint32_t m = n >> 1; m >= 1; m >>= 1) {
+        for (uint32_t i = 0; i < m; i++) {
+            uint32_t j1 = 2 * i * t;
+            const orc_u256 *w = &p->itw_m[m + i];
+            for (uint32_t j = j1; j < j1 + t; j++) orc_gs_butterfly(&x[j], &x[j + t], w, &p->q, p->inv0);
+        }
+        t <<= 1;
+    }
+    for (uint32_t j = 0; j < n; j++) { orc_u256 v = x[j]; orc_mont_mul(&x[j], &v, &p->n_inv_m, &p->q, p->inv0); }
+}
+
+void orc_ntt_pointwise(const orc_plan *p, orc_u256 *r, const orc_u256 *a, const orc_u256 *b) {
+    for (uint32_t j = 0; j < p->n; j++) {
+        orc_u256 t; orc_mont_mul(&t, &a[j], &b[j], &p->q, p->inv0);   /* a*b*R^-1 */
+        orc_mont_mul(&r[j], &t, &p->r2, &p->q, p->inv0);              /* back to plain */
+    }
+}
+
+void orc_polymul_ntt(const orc_plan *p, orc_u256 *r, const orc_u256 *a, const orc_u256 *b) {
+    size_t bytes = (size_t)p->n * sizeof(orc_u256);
+    orc_u256 *ta = (orc_u256 *)malloc(bytes), *tb = (orc_u256 *)malloc(bytes);
+    memcpy(ta, a, bytes); memcpy(tb, b, bytes);                       /* src/ntt.cu:51-58 */
+    orc_ntt_forward(p, ta); orc_ntt_forward(p, tb);
+    orc_ntt_pointwise(p, r, ta, tb);
+    orc_ntt_inverse(p, r);
+    free(ta); free(tb);
+}
+
+void orc_polymul_schoolbook(const orc_plan *p, orc_u256 *r, const orc_u256 *a, const orc_u256 *b) {
+    uint32_t n = p->n;
+    orc_u256 *bm = (orc_u256 *)malloc((size_t)n * sizeof(orc_u256));
+    for (uint32_t j = 0; j < n; j++) to_mont(p, &bm[j], &b[j]);       /* mont(a, bR) = a*b */
+    memset(r, 0, (size_t)n * sizeof(orc_u256));
+    for (uint32_t i = 0; i < n; i++) {
+        if (u256_is_zero(&a[i])) continue;
+        for (uint32_t j = 0; j < n; j++) {
+            orc_u256 prod, acc;
+            orc_mont_mul(&prod, &a[i], &bm[j], &p->q, p->inv0);
+            uint32_t k = i + j;
+            if (k < n) orc_add_mod(&acc, &r[k], &prod, &p->q);
+            else { k -= n; orc_sub_mod(&acc, &r[k], &prod, &p->q); }   /* x^n = -1 */
+            r[k] = acc;
+        }
+    }
+    free(bm);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+int orc_max_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+static int clamp_threads(int threads) {
+    int mx = orc_max_threads();
+    if (threads < 1) threads = 1;
+    return threads > mx ? mx : threads;
+}
+
+int orc_rns_forward(orc_plan *const *plans, uint32_t L, orc_u256 *data, uint32_t batch, int threads) {
+    threads = clamp_threads(threads);
+    long total = (long)batch * L;
+    #pragma omp parallel for num_threads(threads) schedule(dynamic) if (threads > 1)
+    for (long u = 0; u < total; u++) {
+        const orc_plan *p = plans[u % L];
+        orc_ntt_forward(p, data + (size_t)u * p->n);
+    }
+    return threads;
+}
+
+int orc_rns_inverse(orc_plan *const *plans, uint32_t L, orc_u256 *data, uint32_t batch, int threads) {
+    threads = clamp_threads(threads);
+    long total = (long)batch * L;
+    #pragma omp parallel for num_threads(threads) schedule(dynamic) if (threads > 1)
+    for (long u = 0; u < total; u++) {
+        const orc_plan *p = plans[u % L];
+        orc_ntt_inverse(p, data + (size_t)u * p->n);
+    }
+    return threads;
+}
+
+int orc_rns_polymul(orc_plan *const *plans, uint32_t L, orc_u256 *r, const orc_u256 *a, const orc_u256 *b,
+                    uint32_t batch, int threads) {
+    threads = clamp_threads(threads);
+    long total = (long)batch * L;
+    #pragma omp parallel for num_threads(threads) schedule(dynamic) if (threads > 1)
+    for (long u = 0; u < total; u++) {
+        const orc_plan *p = plans[u % L];
+        size_t off = (size_t)u * p->n;
+        orc_polymul_ntt(p, r + off, a + off, b + off);
+    }
+    return threads;
+}
+
+int orc_ct_multiply(orc_plan *const *plans, uint32_t L, orc_u256 *c0, orc_u256 *c1, orc_u256 *c2,
+                    const orc_u256 *a0, const orc_u256 *a1, const orc_u256 *b0, const orc_u256 *b1,
+                    uint32_t batch, int threads) {
+    threads = clamp_threads(threads);
+    long total = (long)batch * L;
+    #pragma omp parallel for num_threads(threads) schedule(dynamic) if (threads > 1)
+    for (long u = 0; u < total; u++) {
+        const orc_plan *p = plans[u % L];
+        size_t off = (size_t)u * p->n, bytes = (size_t)p->n * sizeof(orc_u256);
+        orc_u256 *t1 = (orc_u256 *)malloc(bytes), *t2 = (orc_u256 *)malloc(bytes);
+        orc_polymul_ntt(p, c0 + off, a0 + off, b0 + off);              /* src/fhe.cu:208 */
+        orc_polymul_ntt(p, t1, a0 + off, b1 + off);                    /* :211-212 */
+        orc_polymul_ntt(p, t2, a1 + off, b0 + off);                    /* :213 */
+        orc_batch_add(c1 + off, t1, t2, &p->q, p->n);                  /* :214 */
+        orc_polymul_ntt(p, c2 + off, a1 + off, b1 + off);              /* :217 */
+        free(t1); free(t2);
+    }
+    return threads;
+}

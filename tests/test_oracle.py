@@ -1,0 +1,223 @@
+"""CPU tests that pin the oracle (oracle/fhe_oracle.c) before anything is compared against it.
+
+Level L0/L1: the reference's own known answers (tests/golden/reference_kats.json) + an independent
+Python big-int closed form.  Level L2: the direct O(n^2) mathematics.
+"""
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+
+import ntt_math as nm
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def kats():
+    with open(os.path.join(HERE, "golden", "reference_kats.json")) as f:
+        return json.load(f)
+
+
+# ---------------------------------------------------------------------------------- L0 known answers
+def test_reference_test_file_known_answers(oracle, kats):
+    for c in kats["reference_tests"]["add_mod"]:
+        assert oracle.add_mod(int(c["a"]), int(c["b"]), int(c["q"])) == int(c["r"])
+    for c in kats["reference_tests"]["sub_mod"]:
+        assert oracle.sub_mod(int(c["a"]), int(c["b"]), int(c["q"])) == int(c["r"])
+
+
+def test_survey_primitive_kats(oracle, kats):
+    for c in kats["survey_appendix_b"]["primitives"]:
+        q = int(c["q"])
+        assert oracle.mont_inverse(q) == int(c["inv0"], 16)
+        assert oracle.mont_mul(5, 7, q) == int(c["mont_5_7"])
+        assert oracle.mont_mul(q - 1, q - 1, q) == int(c["mont_qm1_qm1"])
+        assert oracle.add_mod(q - 1, q - 1, q) == int(c["add_qm1_qm1"])
+        assert oracle.sub_mod(0, 1, q) == int(c["sub_0_1"])
+    e = kats["survey_appendix_b"]["even_modulus_inverse"]
+    assert oracle.mont_inverse(int(e["q"])) == int(e["inv0"], 16)
+    k = kats["survey_appendix_b"]["constants"]
+    assert pow(2, 256, 12289) == int(k["R_mod_12289"])
+    assert pow(2, 512, 12289) == int(k["R2_mod_12289"])
+    assert pow(2, 256, 40961) == int(k["R_mod_40961"])
+
+
+def test_survey_literal_kernel_kats(oracle, kats):
+    """L1: reference kernels with the placeholder tables the reference really builds."""
+    for c in kats["survey_appendix_b"]["literal_kernels_placeholder_tables"]:
+        n, q = c["n"], int(c["q"])
+        tw = oracle.ref_placeholder_table(n)
+        x = oracle.to_limbs(range(1, n + 1))
+        f = oracle.ref_forward_kernel(x, tw, q)
+        assert oracle.from_limbs(f)[:8] == c["forward_first8"]
+        i = oracle.ref_inverse_kernel(f, tw, q, int(c["n_inv"]))
+        assert oracle.from_limbs(i)[:8] == c["then_inverse_first8"]
+
+
+# ---------------------------------------------------------------------------------- L0 closed form
+def _moduli():
+    rng = random.Random(1234)
+    ms = [12289, 40961, (1 << 39) + 1, 100000 + 1]
+    ms += nm.ntt_primes(30, 8192, 2) + nm.ntt_primes(60, 8192, 1)
+    for bits in (61, 64, 65, 120, 128, 129, 192, 193, 254, 255):
+        ms.append(rng.getrandbits(bits) | (1 << (bits - 1)) | 1)
+    return ms
+
+
+def test_primitives_match_closed_form(oracle):
+    rng = random.Random(99)
+    for q in _moduli():
+        edge = [0, 1, 2, q - 1, q - 2, q // 2, q, q + 1, (1 << 256) - 1, (1 << 255), rng.getrandbits(256)]
+        ops = [(a, b) for a in edge for b in edge]
+        ops += [(rng.randrange(q), rng.randrange(q)) for _ in range(200)]
+        ops += [(rng.getrandbits(256), rng.getrandbits(256)) for _ in range(50)]   # unreduced: still literal
+        inv0 = nm.mont_inverse_ref(q)
+        assert oracle.mont_inverse(q) == inv0
+        A = oracle.to_limbs([a for a, _ in ops]); B = oracle.to_limbs([b for _, b in ops])
+        got_add = oracle.from_limbs(oracle.batch_add(A, B, q))
+        got_sub = oracle.from_limbs(oracle.batch_sub(A, B, q))
+        got_mul = oracle.from_limbs(oracle.batch_mont(A, B, q))
+        for (a, b), ga, gs, gm in zip(ops, got_add, got_sub, got_mul):
+            assert ga == nm.add_mod_ref(a, b, q)
+            assert gs == nm.sub_mod_ref(a, b, q)
+            assert gm == nm.mont_mul_ref(a, b, q, inv0)
+        # reduced operands: Montgomery product is a*b*R^-1 mod q, canonical
+        rinv = pow(nm.R, -1, q) if nm.is_prime(q) or np.gcd(q % (1 << 62), 2) == 1 else None
+        try:
+            rinv = pow(nm.R, -1, q)
+        except ValueError:
+            rinv = None
+        if rinv is not None:
+            for _ in range(50):
+                a, b = rng.randrange(q), rng.randrange(q)
+                assert oracle.mont_mul(a, b, q) == a * b * rinv % q
+
+
+def test_butterflies_match_closed_form(oracle):
+    rng = random.Random(7)
+    for q in _moduli():
+        for _ in range(40):
+            a, b, w = rng.randrange(q), rng.randrange(q), rng.randrange(q)
+            assert oracle.ct_butterfly(a, b, w, q) == nm.ct_ref(a, b, w, q)
+            assert oracle.gs_butterfly(a, b, w, q) == nm.gs_ref(a, b, w, q)
+
+
+def test_garbage_even_modulus_is_literal(oracle):
+    """q = 2^60 (what FHEContext really passes, src/fhe.cu:13): deterministic garbage, still literal."""
+    q = 1 << 60
+    rng = random.Random(5)
+    for _ in range(50):
+        a, b = rng.randrange(q), rng.randrange(q)
+        assert oracle.mont_mul(a, b, q) == nm.mont_mul_ref(a, b, q)
+
+
+# ---------------------------------------------------------------------------------- L1 with real tables
+def test_literal_kernels_with_proper_tables_are_a_cyclic_dft(oracle):
+    """with tw[k] = psi^k * R the reference forward kernel is the cyclic DFT (omega =
+    psi^2) of the bit-reversed input, and the inverse kernel undoes it."""
+    q = 12289
+    for n in (8, 64, 1024):
+        psi = nm.find_psi(n, q)
+        Rm = nm.R % q
+        tw = oracle.to_limbs([pow(psi, k, q) * Rm % q for k in range(n)])
+        itw = oracle.to_limbs([pow(psi, -k, q) * Rm % q for k in range(n)])
+        n_inv_m = pow(n, -1, q) * Rm % q
+        rng = random.Random(n)
+        x = [rng.randrange(q) for _ in range(n)]
+        bits = n.bit_length() - 1
+        xb = [x[nm.bitrev(i, bits)] for i in range(n)]
+        f = oracle.from_limbs(oracle.ref_forward_kernel(oracle.to_limbs(xb), tw, q))
+        if n <= 64:
+            om = psi * psi % q
+            want = [sum(x[j] * pow(om, j * k, q) for j in range(n)) % q for k in range(n)]
+            assert f == want
+        back = oracle.from_limbs(oracle.ref_inverse_kernel(oracle.to_limbs(f), itw, q, n_inv_m))
+        # The reference never un-permutes after the GS network; the data comes back bit-reversed (D6).
+        assert back == xb or back == x
+
+
+# ---------------------------------------------------------------------------------- L2 intended maths
+@pytest.mark.parametrize("n,q", [(8, 12289), (64, 12289), (256, 40961), (128, None), (64, "wide")])
+def test_forward_matches_direct_definition(oracle, n, q):
+    if q is None:
+        q = nm.ntt_primes(60, n, 1)[0]
+    if q == "wide":
+        q = nm.ntt_primes(250, n, 1)[0]
+    plan = oracle.Plan(n, q)
+    psi = nm.find_psi(n, q)
+    assert plan.psi == psi
+    bits = n.bit_length() - 1
+    for k in (1, 2, 3, n - 1):
+        assert plan.twiddle(k) == pow(psi, nm.bitrev(k, bits), q)
+    rng = random.Random(n)
+    x = [rng.randrange(q) for _ in range(n)]
+    got = oracle.from_limbs(plan.forward(oracle.to_limbs(x)))
+    assert got == nm.negacyclic_ntt_direct(x, q, psi)
+    assert oracle.from_limbs(plan.inverse(oracle.to_limbs(got))) == x
+
+
+def test_reference_roundtrip_case(oracle):
+    """tests/test_fhe.cu:65-120: N = 1024, q = 12289, data i+1, INTT(NTT(x)) == x."""
+    plan = oracle.Plan(1024, 12289)
+    x = oracle.to_limbs(range(1, 1025))
+    y = plan.forward(x)
+    assert not np.array_equal(x, y)
+    assert np.array_equal(plan.inverse(y), x)
+
+
+@pytest.mark.parametrize("n,bits", [(8, 14), (256, 30), (256, 60), (128, 250)])
+def test_polymul_matches_schoolbook(oracle, n, bits):
+    q = 12289 if bits == 14 else nm.ntt_primes(bits, n, 1)[0]
+    plan = oracle.Plan(n, q)
+    rng = random.Random(bits)
+    a = [rng.randrange(q) for _ in range(n)]; b = [rng.randrange(q) for _ in range(n)]
+    A, B = oracle.to_limbs(a), oracle.to_limbs(b)
+    want = nm.negacyclic_mul_direct(a, b, q)
+    assert oracle.from_limbs(plan.polymul(A, B)) == want
+    assert oracle.from_limbs(plan.schoolbook(A, B)) == want
+    assert np.array_equal(A, oracle.to_limbs(a))       # operands preserved (src/ntt.cu:50-58)
+
+
+def test_polymul_reference_shape_n2048(oracle):
+    """tests/test_fhe.cu:126-167: N = 2048, q = 40961, coefficients rand()%100 (result never read back
+    there; here it is checked against the C schoolbook oracle)."""
+    plan = oracle.Plan(2048, 40961)
+    rng = random.Random(2048)
+    A = oracle.to_limbs(rng.randrange(100) for _ in range(2048))
+    B = oracle.to_limbs(rng.randrange(100) for _ in range(2048))
+    assert np.array_equal(plan.polymul(A, B), plan.schoolbook(A, B))
+
+
+def test_rns_layout_and_threads(oracle):
+    n, L, batch = 64, 3, 4
+    moduli = nm.ntt_primes(30, n, L)
+    rp = oracle.RnsPlan(n, moduli)
+    rng = np.random.default_rng(3)
+    a = np.zeros((batch, L, n, 4), np.uint64); b = np.zeros_like(a)
+    for l, q in enumerate(moduli):
+        a[:, l, :, 0] = rng.integers(0, q, (batch, n), dtype=np.uint64)
+        b[:, l, :, 0] = rng.integers(0, q, (batch, n), dtype=np.uint64)
+    r1 = rp.polymul(a, b, threads=1); r2 = rp.polymul(a, b, threads=2)
+    assert np.array_equal(r1, r2)
+    for bi in range(batch):
+        for l in range(L):
+            assert np.array_equal(r1[bi, l], rp.plans[l].polymul(a[bi, l], b[bi, l]))
+    f = rp.forward(a, threads=2)
+    assert np.array_equal(rp.inverse(f, threads=2), a)
+    c0, c1, c2 = rp.ct_multiply(a, b, b, a, threads=2)
+    assert np.array_equal(c0, rp.polymul(a, b)) and np.array_equal(c2, rp.polymul(b, a))
+    q0 = moduli[0]
+    want_c1 = oracle.batch_add(np.ascontiguousarray(rp.polymul(a, a)[:, 0]), np.ascontiguousarray(rp.polymul(b, b)[:, 0]), q0)
+    assert np.array_equal(c1[:, 0], want_c1)
+
+
+def test_plan_rejects_bad_moduli(oracle):
+    with pytest.raises(ValueError):
+        oracle.Plan(1024, 12289 + 2)       # not 1 mod 2n
+    with pytest.raises(ValueError):
+        oracle.Plan(1000, 12289)           # n not a power of two
+    with pytest.raises(ValueError):
+        oracle.Plan(8, (1 << 39) + 1)      # composite (3^2 * 2731 * 22366891): what src/rns.cu:199-204 returns
