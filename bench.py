@@ -1,0 +1,165 @@
+#!/usr/bin/env python3
+"""bench.py -- NTT-polymul/sec at N = 8192 with 4 RNS limbs (BASELINE.json configs[1]) on MI355X.
+
+One "step" = one pass of the hot path over one batch of synthetic RNS polynomials resident in HBM:
+    r = a (*) b  mod (x^N + 1, q_0..q_{L-1})          fhe_rns_ntt_multiply  (NTTEngine::multiply, src/ntt.cu:49-75)
+for `--batch` polynomial pairs per GPU ([batch][L][N] 32-byte containers, 30-bit NTT primes = log_q 120 / 4).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
+
+Prints ONE JSON line on rank 0.  `value` = polynomial products per second over all GPUs (weak
+scaling: every rank multiplies its own `--batch` pairs; the path has no exchange step, so RCCL is used
+only for the barriers and the max-over-ranks of the timings).  `roofline` is measured live with HIP
+events on the engine's stream; `cpu_baseline` times the CPU oracle (a port, not the product) on a
+bounded sample.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 measured copy)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=1024, help="polynomial pairs per GPU per step")
+    ap.add_argument("--n", type=int, default=8192)
+    ap.add_argument("--limbs", type=int, default=4)
+    ap.add_argument("--bits", type=int, default=30, help="bit length of each RNS prime (30 = log_q 120 / 4 limbs)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--extras", action="store_true", help="also time forward+inverse pairs and the ciphertext tensor product")
+    return ap.parse_args()
+
+
+def fill_device(pkg, buf, seed, moduli, n, batch, chunk=64):
+    """Seeded residues, generated on the host in chunks and uploaded (outside any timed region)."""
+    import ctypes
+    from workload import rns_poly
+    per = len(moduli) * n * 32
+    for b0 in range(0, batch, chunk):
+        nb = min(chunk, batch - b0)
+        arr = rns_poly(seed + b0, moduli, n, nb)
+        rc = pkg.lib().fhe_hip_memcpy_h2d(buf.ptr + b0 * per, arr.ctypes.data, arr.nbytes)
+        if rc:
+            raise RuntimeError(pkg.lib().fhe_hip_last_error().decode())
+
+
+def cpu_baseline(n, moduli, target_core_seconds=16.0):
+    """CPU oracle (oracle/fhe_oracle.c, OpenMP over batch x limb) on a bounded sample of the same workload."""
+    from oracle import pyoracle as orc
+    from workload import rns_poly
+    orc.build()
+    cores = min(orc.max_threads(), os.cpu_count() or 1)
+    rp = orc.RnsPlan(n, moduli)
+    a = rns_poly(7, moduli, n, 1); b = rns_poly(8, moduli, n, 1)
+    t0 = time.perf_counter(); rp.polymul(a, b, threads=1); one = time.perf_counter() - t0
+    sample = max(cores, int(target_core_seconds / max(one, 1e-6)))
+    sample = min(sample, 4096)
+    a = rns_poly(7, moduli, n, sample); b = rns_poly(8, moduli, n, sample)
+    t0 = time.perf_counter(); rp.polymul(a, b, threads=cores); dt = time.perf_counter() - t0
+    return {"value": sample / dt, "unit": "polymul/s", "cores": int(rp.threads_used), "kind": "port",
+            "sample": f"{sample} polymuls of N={n}, L={len(moduli)} (oracle/fhe_oracle.c, 256-bit Montgomery, "
+                      f"OpenMP over batch x limb; single-thread {one * 1e3:.1f} ms/polymul)"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch                       # first, so the process has ONE libamdhip64 (same SONAME as ours)
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    pkg = importlib.import_module("gpu-homomorphic-encryption_amd")
+    if pkg.device_count() < 1:
+        raise SystemExit("bench.py: no HIP device; the engine has no CPU fallback")
+    if world > 1:
+        rc = pkg.lib().fhe_hip_set_device(local_rank)
+        assert rc == 0, pkg.lib().fhe_hip_last_error()
+
+    n, L, B = args.n, args.limbs, args.batch
+    moduli = pkg.find_ntt_primes(args.bits, n, L)
+    eng = pkg.RnsNttEngine(n, moduli)
+    S = 32 * n * L                                   # bytes of one RNS polynomial
+    dA, dB, dR = pkg.DeviceBuffer(B * S), pkg.DeviceBuffer(B * S), pkg.DeviceBuffer(B * S)
+    fill_device(pkg, dA, 1000 + rank * 100000, moduli, n, B)
+    fill_device(pkg, dB, 5000 + rank * 100000, moduli, n, B)
+    dR.zero()
+
+    def barrier():
+        pkg.capi.sync()
+        if dist is not None:
+            dist.barrier()
+            pkg.capi.sync()
+
+    def timed(fn, steps, warmup):
+        for _ in range(warmup):
+            fn()
+        timer = pkg.Timer()
+        barrier()
+        t0 = time.perf_counter()
+        timer.start(eng)
+        for _ in range(steps):
+            fn()
+        timer.stop(eng)
+        pkg.capi.sync()
+        if dist is not None:
+            dist.barrier()
+        wall = time.perf_counter() - t0
+        ev_ms = timer.elapsed_ms()
+        if dist is not None:
+            import torch
+            t = torch.tensor([wall, ev_ms], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            wall, ev_ms = float(t[0]), float(t[1])
+        return wall, ev_ms
+
+    wall, ev_ms = timed(lambda: eng.multiply(dR, dA, dB, B), args.steps, args.warmup)
+    ms_per_step = wall * 1e3 / args.steps
+    value = B * world / (wall / args.steps)
+    launch_ms = ev_ms / args.steps                   # one kernel launch per step on the 32/64-bit paths
+    algo_bytes = 3 * S * B                           # read a, read b, write r  (3*S per polymul)
+    achieved = algo_bytes / (launch_ms * 1e-3) / 1e9
+    width = {1: "u32", 2: "u64", 4: "u256"}[eng.width_class]
+    out = {
+        "metric": "NTT-polymul/sec (N=8192, 4 RNS limbs) + achieved HBM GB/s vs peak",
+        "value": value, "unit": "polymul/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": width, "data": "synthetic",
+        "config": {"workload": f"configs[1]: forward+inverse NTT + pointwise mul (fused polymul), N={n}, {L} RNS limbs "
+                               f"({args.bits}-bit primes), batch {B} polynomial pairs per GPU, 32-byte containers",
+                   "n": n, "limbs": L, "prime_bits": args.bits, "batch_per_gpu": B, "parallelism": f"batch-shard x{world}"},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "kernel": "ntt_multiply_kernel", "launch_ms": launch_ms, "algorithmic_bytes_per_launch": algo_bytes},
+    }
+    if args.extras:
+        w2, e2 = timed(lambda: (eng.forward(dA, B), eng.inverse(dA, B)), args.steps, args.warmup)
+        pair_ms = e2 / args.steps
+        out["extra_fwd_inv_pairs"] = {"pairs_per_s": B * world / (w2 / args.steps), "achieved_GBps": 4 * S * B / (pair_ms * 1e-3) / 1e9,
+                                      "frac": 4 * S * B / (pair_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(n, moduli)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,34 @@
+"""Builds lib/libfhe_hip.so with hipcc for gfx950 (cross-compiles without a GPU)."""
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_CSRC = os.path.join(_HERE, "csrc")
+_LIB = os.path.join(_HERE, "lib", "libfhe_hip.so")
+
+
+def library_path():
+    return _LIB
+
+
+def _sources():
+    out = [os.path.join(_CSRC, f) for f in os.listdir(_CSRC)]
+    out.append(os.path.join(os.path.dirname(_HERE), "include", "fhe_hip.h"))
+    return [p for p in out if os.path.isfile(p)]
+
+
+def build_library(force=False, jobs=None, verbose=False):
+    """make -C csrc.  Skips the build when the library is newer than every source (the GPU box has
+    the prebuilt .so from the snapshot and need not rebuild)."""
+    if not force and os.path.exists(_LIB):
+        newest = max(os.path.getmtime(s) for s in _sources())
+        if os.path.getmtime(_LIB) >= newest:
+            return _LIB
+    jobs = jobs or min(8, os.cpu_count() or 1)
+    cmd = ["make", "-C", _CSRC, f"-j{jobs}"]
+    if force:
+        cmd.append("-B")
+    res = subprocess.run(cmd, capture_output=not verbose, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("libfhe_hip.so build failed:\n" + (res.stdout or "") + (res.stderr or ""))
+    return _LIB

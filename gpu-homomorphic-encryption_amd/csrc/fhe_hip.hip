@@ -1,0 +1,605 @@
+// fhe_hip.hip -- implementation of the C ABI in include/fhe_hip.h (gfx950 only, no CPU fallback).
+#include "../../include/fhe_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "host_math.hpp"
+#include "ntt256.hip.h"
+#include "lds_launch.h"
+#include "ntt_lds.hip.h"
+
+using fhe_host::U256;
+
+// ------------------------------------------------------------------------------------------------------
+// error plumbing
+// ------------------------------------------------------------------------------------------------------
+static thread_local std::string g_last_error;
+
+static int fail(int code, const std::string &msg) { g_last_error = msg; return code; }
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail(FHE_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));           \
+    } while (0)
+
+static bool env_sync() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("FHE_HIP_SYNC"); v = (e && e[0] == '1') ? 1 : 0; }
+    return v == 1;
+}
+
+static int ensure_device() {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        return fail(FHE_ERR_NO_DEVICE, std::string("no usable HIP device (hipGetDeviceCount: ") +
+                                           (e == hipSuccess ? "0 devices" : hipGetErrorString(e)) +
+                                           "); this library has no CPU fallback");
+    }
+    return FHE_OK;
+}
+
+static int post_launch(hipStream_t s, const char *what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(FHE_ERR_HIP, std::string(what) + " launch: " + hipGetErrorString(e));
+    if (env_sync()) {
+        e = hipStreamSynchronize(s);
+        if (e != hipSuccess) return fail(FHE_ERR_HIP, std::string(what) + " sync: " + hipGetErrorString(e));
+    }
+    return FHE_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// plumbing entry points
+// ------------------------------------------------------------------------------------------------------
+extern "C" int fhe_hip_abi_version(void) { return FHE_HIP_ABI_VERSION; }
+extern "C" const char *fhe_hip_last_error(void) { return g_last_error.c_str(); }
+
+extern "C" int fhe_hip_device_count(int *count) {
+    if (!count) return fail(FHE_ERR_INVALID_ARG, "count is null");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { (void)hipGetLastError(); *count = 0; return fail(FHE_ERR_NO_DEVICE, hipGetErrorString(e)); }
+    *count = n;
+    return FHE_OK;
+}
+extern "C" int fhe_hip_set_device(int device) {
+    int rc = ensure_device(); if (rc) return rc;
+    HIP_TRY(hipSetDevice(device));
+    return FHE_OK;
+}
+extern "C" int fhe_hip_get_device(int *device) {
+    if (!device) return fail(FHE_ERR_INVALID_ARG, "device is null");
+    int rc = ensure_device(); if (rc) return rc;
+    HIP_TRY(hipGetDevice(device));
+    return FHE_OK;
+}
+extern "C" int fhe_hip_device_name(char *buf, size_t buflen) {
+    if (!buf || !buflen) return fail(FHE_ERR_INVALID_ARG, "buf is null");
+    int rc = ensure_device(); if (rc) return rc;
+    int dev = 0; HIP_TRY(hipGetDevice(&dev));
+    hipDeviceProp_t prop; HIP_TRY(hipGetDeviceProperties(&prop, dev));
+    snprintf(buf, buflen, "%s %s (%d CUs)", prop.gcnArchName, prop.name, prop.multiProcessorCount);
+    return FHE_OK;
+}
+extern "C" int fhe_hip_malloc(void **d_ptr, size_t bytes) {
+    if (!d_ptr) return fail(FHE_ERR_INVALID_ARG, "d_ptr is null");
+    int rc = ensure_device(); if (rc) return rc;
+    HIP_TRY(hipMalloc(d_ptr, bytes ? bytes : 1));
+    return FHE_OK;
+}
+extern "C" int fhe_hip_free(void *d_ptr) { if (d_ptr) HIP_TRY(hipFree(d_ptr)); return FHE_OK; }
+extern "C" int fhe_hip_memset(void *d_ptr, int value, size_t bytes) { HIP_TRY(hipMemset(d_ptr, value, bytes)); return FHE_OK; }
+extern "C" int fhe_hip_memcpy_h2d(void *d, const void *h, size_t bytes) { HIP_TRY(hipMemcpy(d, h, bytes, hipMemcpyHostToDevice)); return FHE_OK; }
+extern "C" int fhe_hip_memcpy_d2h(void *h, const void *d, size_t bytes) { HIP_TRY(hipMemcpy(h, d, bytes, hipMemcpyDeviceToHost)); return FHE_OK; }
+extern "C" int fhe_hip_memcpy_d2d(void *d, const void *s, size_t bytes) { HIP_TRY(hipMemcpy(d, s, bytes, hipMemcpyDeviceToDevice)); return FHE_OK; }
+extern "C" int fhe_hip_sync(void) { int rc = ensure_device(); if (rc) return rc; HIP_TRY(hipDeviceSynchronize()); return FHE_OK; }
+
+// ------------------------------------------------------------------------------------------------------
+// host parameter maths (no device needed)
+// ------------------------------------------------------------------------------------------------------
+extern "C" int fhe_montgomery_inverse(const uint64_t q[4], uint64_t inv[4]) {
+    if (!q || !inv) return fail(FHE_ERR_INVALID_ARG, "null argument");
+    // literal: 6 Newton steps on the low limb from x = 1, negated (src/bigint.cu:27-37); garbage for even q
+    inv[0] = fhe_host::neg_inv64(q[0]); inv[1] = inv[2] = inv[3] = 0;
+    return FHE_OK;
+}
+extern "C" int fhe_montgomery_params(const uint64_t q[4], uint64_t r_squared[4], uint64_t inv[4]) {
+    if (!q || !r_squared || !inv) return fail(FHE_ERR_INVALID_ARG, "null argument");
+    U256 Q = U256::from(q);
+    if (!(Q.w[0] & 1) || (Q.w[3] >> 63) || Q.bit_length() < 2) return fail(FHE_ERR_BAD_MODULUS, "modulus must be odd, > 1 and < 2^255");
+    fhe_host::Mod M(Q);
+    std::memcpy(r_squared, M.r2.w, 32);
+    return fhe_montgomery_inverse(q, inv);
+}
+extern "C" int fhe_find_ntt_primes(uint32_t bits, uint32_t n, uint32_t count, uint64_t *primes_out) {
+    if (!primes_out || !count) return fail(FHE_ERR_INVALID_ARG, "null output / zero count");
+    if (!fhe_host::find_ntt_primes(bits, n, count, primes_out))
+        return fail(FHE_ERR_INVALID_ARG, "no such primes (need 4 <= bits <= 64, n a power of two, 2n < 2^(bits-1))");
+    return FHE_OK;
+}
+extern "C" int fhe_find_psi(uint32_t n, const uint64_t q[4], uint64_t psi[4]) {
+    if (!q || !psi) return fail(FHE_ERR_INVALID_ARG, "null argument");
+    if (n < 2 || (n & (n - 1))) return fail(FHE_ERR_INVALID_ARG, "n must be a power of two");
+    U256 Q = U256::from(q);
+    if (!(Q.w[0] & 1) || (Q.w[3] >> 63) || !fhe_host::is_prime(Q)) return fail(FHE_ERR_BAD_MODULUS, "modulus must be an odd prime < 2^255");
+    fhe_host::Mod M(Q); U256 p;
+    if (fhe_host::find_psi(n, M, p) != fhe_host::BUILD_OK) return fail(FHE_ERR_BAD_MODULUS, "q != 1 (mod 2n): no primitive 2n-th root");
+    std::memcpy(psi, p.w, 32);
+    return FHE_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// literal element-wise kernels
+// ------------------------------------------------------------------------------------------------------
+static fhe_dev::u256 to_dev(const uint64_t q[4]) { fhe_dev::u256 r; std::memcpy(r.l, q, 32); return r; }
+
+static unsigned ew_grid(size_t items) {
+    size_t blocks = (items + 255) / 256;
+    return (unsigned)(blocks < 1 ? 1 : (blocks > 8192 ? 8192 : blocks));   // grid-stride above 8192 blocks
+}
+
+template <int OP>
+static int launch_ew256(void *d_r, const void *d_a, const void *d_b, const uint64_t q[4], const uint64_t *scalar,
+                        uint64_t inv0, size_t count, void *stream, const char *what) {
+    if (!d_r || !d_a || (OP != 3 && !d_b) || !q) return fail(FHE_ERR_INVALID_ARG, std::string(what) + ": null argument");
+    int rc = ensure_device(); if (rc) return rc;
+    if (!count) return FHE_OK;
+    hipStream_t s = (hipStream_t)stream;
+    fhe_dev::u256 Q = to_dev(q), S = scalar ? to_dev(scalar) : Q;
+    hipLaunchKernelGGL(fhe_dev::ew256_kernel<OP>, dim3(ew_grid(count)), dim3(256), 0, s, (fhe_dev::u256 *)d_r,
+                       (const fhe_dev::u256 *)d_a, (const fhe_dev::u256 *)d_b, Q, S, inv0, count);
+    return post_launch(s, what);
+}
+extern "C" int fhe_u256_add_mod(void *r, const void *a, const void *b, const uint64_t q[4], size_t count, void *stream) {
+    return launch_ew256<1>(r, a, b, q, nullptr, 0, count, stream, "fhe_u256_add_mod");
+}
+extern "C" int fhe_u256_sub_mod(void *r, const void *a, const void *b, const uint64_t q[4], size_t count, void *stream) {
+    return launch_ew256<2>(r, a, b, q, nullptr, 0, count, stream, "fhe_u256_sub_mod");
+}
+extern "C" int fhe_u256_mont_mul(void *r, const void *a, const void *b, const uint64_t q[4], uint64_t inv0, size_t count, void *stream) {
+    return launch_ew256<0>(r, a, b, q, nullptr, inv0, count, stream, "fhe_u256_mont_mul");
+}
+extern "C" int fhe_u256_mont_mul_scalar(void *r, const void *a, const uint64_t scalar[4], const uint64_t q[4], uint64_t inv0, size_t count, void *stream) {
+    if (!scalar) return fail(FHE_ERR_INVALID_ARG, "scalar is null");
+    return launch_ew256<3>(r, a, nullptr, q, scalar, inv0, count, stream, "fhe_u256_mont_mul_scalar");
+}
+
+// ------------------------------------------------------------------------------------------------------
+// engine handle
+// ------------------------------------------------------------------------------------------------------
+struct fhe_rns_ntt {
+    int device = 0;
+    uint32_t n = 0, log_n = 0, L = 0;
+    int width = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    void *d_limbs = nullptr;
+    std::vector<void *> d_tables;
+    void *d_ws = nullptr; size_t ws_bytes = 0;
+    uint32_t *d_flag = nullptr;
+    std::vector<U256> moduli;
+};
+struct fhe_ntt { fhe_rns_ntt *impl; };
+
+static void destroy_impl(fhe_rns_ntt *h) {
+    if (!h) return;
+    for (void *p : h->d_tables) (void)hipFree(p);
+    if (h->d_limbs) (void)hipFree(h->d_limbs);
+    if (h->d_ws) (void)hipFree(h->d_ws);
+    if (h->d_flag) (void)hipFree(h->d_flag);
+    if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+    delete h;
+}
+
+template <class T>
+static int upload(fhe_rns_ntt *h, const std::vector<T> &v, void **out) {
+    void *d = nullptr;
+    HIP_TRY(hipMalloc(&d, v.size() * sizeof(T)));
+    h->d_tables.push_back(d);
+    HIP_TRY(hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    *out = d;
+    return FHE_OK;
+}
+
+static uint32_t shoup32(uint64_t w, uint64_t q) { return (uint32_t)((w << 32) / q); }
+static uint64_t shoup64(uint64_t w, uint64_t q) { return (uint64_t)((((fhe_host::u128)w) << 64) / q); }
+
+static int build_limbs32(fhe_rns_ntt *h, const std::vector<fhe_host::NttConstants> &cs) {
+    std::vector<fhe_dev::Limb32> limbs(h->L);
+    for (uint32_t l = 0; l < h->L; l++) {
+        const fhe_host::NttConstants &c = cs[l];
+        const uint64_t q = c.q.w[0], n = h->n;
+        std::vector<uint2> tw(n), itw(n);
+        for (uint32_t k = 0; k < n; k++) {
+            tw[k] = make_uint2((uint32_t)c.tw[k].w[0], shoup32(c.tw[k].w[0], q));
+            itw[k] = make_uint2((uint32_t)c.itw[k].w[0], shoup32(c.itw[k].w[0], q));
+        }
+        fhe_dev::Limb32 &P = limbs[l];
+        std::memset(&P, 0, sizeof(P));
+        P.q = (uint32_t)q; P.q2 = (uint32_t)(2 * q);
+        uint32_t x = 1; for (int i = 0; i < 5; i++) x *= 2 - (uint32_t)q * x;     // q^-1 mod 2^32
+        P.qinv = x;
+        const uint64_t two32 = (1ull << 32) % q, ninv = c.n_inv.w[0], w1 = c.itw[1].w[0];
+        auto mulq = [q](uint64_t a, uint64_t b) { return (uint64_t)(((fhe_host::u128)a * b) % q); };
+        P.r1 = (uint32_t)two32; P.r1_s = shoup32(two32, q);
+        P.ninv = (uint32_t)ninv; P.ninv_s = shoup32(ninv, q);
+        uint64_t nw = mulq(ninv, w1);
+        P.ninvw = (uint32_t)nw; P.ninvw_s = shoup32(nw, q);
+        uint64_t nr = mulq(ninv, two32), nwr = mulq(nw, two32);
+        P.ninv_r = (uint32_t)nr; P.ninv_r_s = shoup32(nr, q);
+        P.ninvw_r = (uint32_t)nwr; P.ninvw_r_s = shoup32(nwr, q);
+        void *d = nullptr; int rc;
+        if ((rc = upload(h, tw, &d))) return rc; P.tw = (const uint2 *)d;
+        if ((rc = upload(h, itw, &d))) return rc; P.itw = (const uint2 *)d;
+    }
+    return upload(h, limbs, &h->d_limbs);
+}
+
+static int build_limbs64(fhe_rns_ntt *h, const std::vector<fhe_host::NttConstants> &cs) {
+    std::vector<fhe_dev::Limb64> limbs(h->L);
+    for (uint32_t l = 0; l < h->L; l++) {
+        const fhe_host::NttConstants &c = cs[l];
+        const uint64_t q = c.q.w[0], n = h->n;
+        std::vector<ulonglong2> tw(n), itw(n);
+        for (uint32_t k = 0; k < n; k++) {
+            tw[k] = make_ulonglong2(c.tw[k].w[0], shoup64(c.tw[k].w[0], q));
+            itw[k] = make_ulonglong2(c.itw[k].w[0], shoup64(c.itw[k].w[0], q));
+        }
+        fhe_dev::Limb64 &P = limbs[l];
+        std::memset(&P, 0, sizeof(P));
+        P.q = q; P.q2 = 2 * q;
+        uint64_t x = 1; for (int i = 0; i < 6; i++) x *= 2 - q * x;               // q^-1 mod 2^64
+        P.qinv = x;
+        auto mulq = [q](uint64_t a, uint64_t b) { return (uint64_t)(((fhe_host::u128)a * b) % q); };
+        const uint64_t two64 = (uint64_t)((((fhe_host::u128)1) << 64) % q), ninv = c.n_inv.w[0], w1 = c.itw[1].w[0];
+        P.r1 = two64; P.r1_s = shoup64(two64, q);
+        P.ninv = ninv; P.ninv_s = shoup64(ninv, q);
+        uint64_t nw = mulq(ninv, w1);
+        P.ninvw = nw; P.ninvw_s = shoup64(nw, q);
+        uint64_t nr = mulq(ninv, two64), nwr = mulq(nw, two64);
+        P.ninv_r = nr; P.ninv_r_s = shoup64(nr, q);
+        P.ninvw_r = nwr; P.ninvw_r_s = shoup64(nwr, q);
+        void *d = nullptr; int rc;
+        if ((rc = upload(h, tw, &d))) return rc; P.tw = (const ulonglong2 *)d;
+        if ((rc = upload(h, itw, &d))) return rc; P.itw = (const ulonglong2 *)d;
+    }
+    return upload(h, limbs, &h->d_limbs);
+}
+
+static int build_limbs256(fhe_rns_ntt *h, const std::vector<fhe_host::NttConstants> &cs) {
+    std::vector<fhe_dev::Limb256> limbs(h->L);
+    for (uint32_t l = 0; l < h->L; l++) {
+        const fhe_host::NttConstants &c = cs[l];
+        fhe_host::Mod M(c.q);
+        std::vector<fhe_dev::u256> tw(h->n), itw(h->n);
+        for (uint32_t k = 0; k < h->n; k++) {
+            U256 a = M.to_mont(c.tw[k]), b = M.to_mont(c.itw[k]);
+            std::memcpy(tw[k].l, a.w, 32); std::memcpy(itw[k].l, b.w, 32);
+        }
+        fhe_dev::Limb256 &P = limbs[l];
+        std::memset(&P, 0, sizeof(P));
+        std::memcpy(P.q.l, c.q.w, 32);
+        std::memcpy(P.r2.l, M.r2.w, 32);
+        U256 nm = M.to_mont(c.n_inv);
+        std::memcpy(P.ninv_m.l, nm.w, 32);
+        P.inv0 = M.inv0;
+        void *d = nullptr; int rc;
+        if ((rc = upload(h, tw, &d))) return rc; P.tw_m = (const fhe_dev::u256 *)d;
+        if ((rc = upload(h, itw, &d))) return rc; P.itw_m = (const fhe_dev::u256 *)d;
+    }
+    return upload(h, limbs, &h->d_limbs);
+}
+
+static int create_impl(fhe_rns_ntt **out, uint32_t n, const uint64_t (*moduli)[4], uint32_t L) {
+    if (!out || !moduli) return fail(FHE_ERR_INVALID_ARG, "null argument");
+    *out = nullptr;
+    if (n < 8 || n > 65536 || (n & (n - 1))) return fail(FHE_ERR_INVALID_ARG, "polynomial degree must be a power of two in [8, 65536]");
+    if (L < 1 || L > 64) return fail(FHE_ERR_INVALID_ARG, "num_primes must be in [1, 64]");
+    std::vector<fhe_host::NttConstants> cs(L);
+    int max_bits = 0;
+    for (uint32_t l = 0; l < L; l++) {
+        U256 q = U256::from(moduli[l]);
+        fhe_host::BuildStatus st = fhe_host::build_constants(n, q, cs[l]);
+        if (st != fhe_host::BUILD_OK) {
+            char buf[160];
+            snprintf(buf, sizeof buf, "modulus %u (low limb 0x%llx) rejected: need an odd prime < 2^255 with q = 1 (mod 2n)", l,
+                     (unsigned long long)q.w[0]);
+            return fail(FHE_ERR_BAD_MODULUS, buf);
+        }
+        if (q.bit_length() > max_bits) max_bits = q.bit_length();
+    }
+    int rc = ensure_device(); if (rc) return rc;
+    fhe_rns_ntt *h = new (std::nothrow) fhe_rns_ntt();
+    if (!h) return fail(FHE_ERR_INVALID_ARG, "out of host memory");
+    h->n = n; h->L = L; while ((1u << h->log_n) < n) h->log_n++;
+    for (uint32_t l = 0; l < L; l++) h->moduli.push_back(cs[l].q);
+    const bool lds_size = h->log_n >= 11 && h->log_n <= 15;
+    const char *force = getenv("FHE_HIP_FORCE_WIDTH");       // testing aid: "256" forces the general path
+    if (force && !strcmp(force, "256")) h->width = FHE_WIDTH_256;
+    else if (lds_size && max_bits <= 30 && !(force && !strcmp(force, "64"))) h->width = FHE_WIDTH_32;
+    else if (lds_size && h->log_n <= 14 && max_bits <= 62) h->width = FHE_WIDTH_64;
+    else h->width = FHE_WIDTH_256;
+#define TRY_OR_DESTROY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { destroy_impl(h); return fail(FHE_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); } } while (0)
+    TRY_OR_DESTROY(hipGetDevice(&h->device));
+    TRY_OR_DESTROY(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
+    h->stream = h->own_stream;
+    TRY_OR_DESTROY(hipMalloc((void **)&h->d_flag, sizeof(uint32_t)));
+    TRY_OR_DESTROY(hipMemset(h->d_flag, 0, sizeof(uint32_t)));
+#undef TRY_OR_DESTROY
+    rc = h->width == FHE_WIDTH_32 ? build_limbs32(h, cs) : h->width == FHE_WIDTH_64 ? build_limbs64(h, cs) : build_limbs256(h, cs);
+    if (rc) { destroy_impl(h); return rc; }
+    *out = h;
+    return FHE_OK;
+}
+
+static int check_call(const fhe_rns_ntt *h, uint32_t batch, const char *what) {
+    if (!h) return fail(FHE_ERR_INVALID_ARG, std::string(what) + ": null handle");
+    if (!batch) return fail(FHE_ERR_INVALID_ARG, std::string(what) + ": batch must be >= 1");
+    if ((uint64_t)batch * h->L > 0x7fffffffull) return fail(FHE_ERR_INVALID_ARG, std::string(what) + ": batch * num_primes too large");
+    return FHE_OK;
+}
+
+static int ensure_ws(fhe_rns_ntt *h, size_t bytes) {
+    if (h->ws_bytes >= bytes) return FHE_OK;
+    // grow-only workspace of the general path (the reference mallocs/frees per multiply, src/ntt.cu:51-74)
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (h->d_ws) { HIP_TRY(hipFree(h->d_ws)); h->d_ws = nullptr; h->ws_bytes = 0; }
+    HIP_TRY(hipMalloc(&h->d_ws, bytes));
+    h->ws_bytes = bytes;
+    return FHE_OK;
+}
+
+// ---- general (256-bit) path launchers -----------------------------------------------------------------
+static int run256_transform(fhe_rns_ntt *h, fhe_dev::u256 *data, uint32_t polys, bool forward) {
+    const uint32_t chunk_max = (65535u / h->L) * h->L;
+    const fhe_dev::Limb256 *limbs = (const fhe_dev::Limb256 *)h->d_limbs;
+    for (uint32_t done = 0; done < polys;) {
+        uint32_t chunk = polys - done < chunk_max ? polys - done : chunk_max;
+        fhe_dev::u256 *d = data + (size_t)done * h->n;
+        for (uint32_t s = 0; s < h->log_n;) {
+            uint32_t R = h->log_n - s >= 2 ? 2 : 1;   // radix-4 passes: radix-8 spills the 8 x 256-bit working set to scratch
+            dim3 grid(((h->n >> R) + 255) / 256, chunk), block(256);
+            if (forward) {
+                if (R == 2) hipLaunchKernelGGL(fhe_dev::ntt256_fwd_pass<2>, grid, block, 0, h->stream, d, limbs, h->L, h->log_n, s);
+                else hipLaunchKernelGGL(fhe_dev::ntt256_fwd_pass<1>, grid, block, 0, h->stream, d, limbs, h->L, h->log_n, s);
+            } else {
+                if (R == 2) hipLaunchKernelGGL(fhe_dev::ntt256_inv_pass<2>, grid, block, 0, h->stream, d, limbs, h->L, h->log_n, s);
+                else hipLaunchKernelGGL(fhe_dev::ntt256_inv_pass<1>, grid, block, 0, h->stream, d, limbs, h->L, h->log_n, s);
+            }
+            s += R;
+        }
+        done += chunk;
+    }
+    return post_launch(h->stream, forward ? "ntt256 forward" : "ntt256 inverse");
+}
+
+template <int OP>
+static int run256_ew(fhe_rns_ntt *h, void *r, const void *a, const void *b, uint32_t polys, const char *what) {
+    size_t count = (size_t)polys * h->n;
+    hipLaunchKernelGGL(fhe_dev::ew256_rns_kernel<OP>, dim3(ew_grid(count)), dim3(256), 0, h->stream, (fhe_dev::u256 *)r,
+                       (const fhe_dev::u256 *)a, (const fhe_dev::u256 *)b, (const fhe_dev::Limb256 *)h->d_limbs, h->L, h->log_n, count);
+    return post_launch(h->stream, what);
+}
+
+// ---- LDS-resident path launchers (kernels live in lds_inst.hip, one object per (field, log2 n)) ---------
+static int lds_run(fhe_rns_ntt *h, int op, void *r0, void *r1, void *r2, const void *a0, const void *a1, const void *b0,
+                   const void *b1, uint32_t polys, const char *what) {
+    fhe_dev::lds_launch_fn fn = fhe_dev::lds_lookup(h->width == FHE_WIDTH_32 ? 32 : 64, (int)h->log_n);
+    if (!fn) return fail(FHE_ERR_UNSUPPORTED, "transform size outside the LDS-resident range");
+    fhe_dev::LdsArgs A{op, r0, r1, r2, a0, a1, b0, b1, h->d_limbs, h->L, polys, h->stream};
+    fn(A);
+    return post_launch(h->stream, what);
+}
+template <class F, int OP>
+static int lds_ew(fhe_rns_ntt *h, void *r, const void *a, const void *b, uint32_t polys, const char *what) {
+    using V = typename F::V16;
+    size_t halves = (size_t)polys * h->n * 2;
+    hipLaunchKernelGGL((fhe_dev::ew_kernel<F, OP>), dim3(ew_grid(halves)), dim3(256), 0, h->stream, (V *)r, (const V *)a,
+                       (const V *)b, (const fhe_dev::Limb<F> *)h->d_limbs, h->L, h->log_n, halves);
+    return post_launch(h->stream, what);
+}
+template <class F>
+static int lds_check(fhe_rns_ntt *h, const void *d, uint32_t polys) {
+    using V = typename F::V16;
+    size_t halves = (size_t)polys * h->n * 2;
+    hipLaunchKernelGGL((fhe_dev::check_kernel<F>), dim3(ew_grid(halves)), dim3(256), 0, h->stream, (const V *)d,
+                       (const fhe_dev::Limb<F> *)h->d_limbs, h->L, h->log_n, halves, h->d_flag);
+    return post_launch(h->stream, "check_kernel");
+}
+
+static int do_forward(fhe_rns_ntt *h, void *d_data, uint32_t batch) {
+    const uint32_t polys = batch * h->L;
+    if (h->width != FHE_WIDTH_256)
+        return lds_run(h, fhe_dev::LDS_FORWARD, d_data, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, polys, "ntt_forward_kernel");
+    return run256_transform(h, (fhe_dev::u256 *)d_data, polys, true);
+}
+static int do_inverse(fhe_rns_ntt *h, void *d_data, uint32_t batch) {
+    const uint32_t polys = batch * h->L;
+    if (h->width != FHE_WIDTH_256)
+        return lds_run(h, fhe_dev::LDS_INVERSE, d_data, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, polys, "ntt_inverse_kernel");
+    return run256_transform(h, (fhe_dev::u256 *)d_data, polys, false);
+}
+template <int OP>
+static int do_ew(fhe_rns_ntt *h, void *r, const void *a, const void *b, uint32_t batch, const char *what) {
+    const uint32_t polys = batch * h->L;
+    if (h->width == FHE_WIDTH_32) return lds_ew<fhe_dev::F32, OP>(h, r, a, b, polys, what);
+    if (h->width == FHE_WIDTH_64) return lds_ew<fhe_dev::F64, OP>(h, r, a, b, polys, what);
+    return run256_ew<OP>(h, r, a, b, polys, what);
+}
+static int do_multiply(fhe_rns_ntt *h, void *d_r, const void *d_a, const void *d_b, uint32_t batch) {
+    const uint32_t polys = batch * h->L;
+    if (d_r == d_a || d_r == d_b) return fail(FHE_ERR_INVALID_ARG, "multiply: result must not alias an operand");
+    if (h->width != FHE_WIDTH_256)
+        return lds_run(h, fhe_dev::LDS_MULTIPLY, d_r, nullptr, nullptr, d_a, nullptr, d_b, nullptr, polys, "ntt_multiply_kernel");
+    // general path: copies keep the operands intact (src/ntt.cu:50-58), one batched forward over both
+    const size_t bytes = (size_t)polys * h->n * 32;
+    int rc = ensure_ws(h, 2 * bytes); if (rc) return rc;
+    char *ws = (char *)h->d_ws;
+    HIP_TRY(hipMemcpyAsync(ws, d_a, bytes, hipMemcpyDeviceToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(ws + bytes, d_b, bytes, hipMemcpyDeviceToDevice, h->stream));
+    if ((rc = run256_transform(h, (fhe_dev::u256 *)ws, 2 * polys, true))) return rc;
+    if ((rc = run256_ew<0>(h, d_r, ws, ws + bytes, polys, "ntt256 pointwise"))) return rc;
+    return run256_transform(h, (fhe_dev::u256 *)d_r, polys, false);
+}
+static int do_ct_multiply(fhe_rns_ntt *h, void *c0, void *c1, void *c2, const void *a0, const void *a1, const void *b0,
+                          const void *b1, uint32_t batch) {
+    const uint32_t polys = batch * h->L;
+    if (h->width != FHE_WIDTH_256)
+        return lds_run(h, fhe_dev::LDS_CT_MULTIPLY, c0, c1, c2, a0, a1, b0, b1, polys, "ntt_ct_multiply_kernel");
+    // general path: 4 forward, 4 products + 1 add in the NTT domain, 3 inverse
+    const size_t bytes = (size_t)polys * h->n * 32;
+    int rc = ensure_ws(h, 5 * bytes); if (rc) return rc;
+    char *ws = (char *)h->d_ws;
+    const void *src[4] = {a0, a1, b0, b1};
+    for (int i = 0; i < 4; i++) HIP_TRY(hipMemcpyAsync(ws + i * bytes, src[i], bytes, hipMemcpyDeviceToDevice, h->stream));
+    if ((rc = run256_transform(h, (fhe_dev::u256 *)ws, 4 * polys, true))) return rc;
+    char *A0 = ws, *A1 = ws + bytes, *B0 = ws + 2 * bytes, *B1 = ws + 3 * bytes, *T = ws + 4 * bytes;
+    if ((rc = run256_ew<0>(h, c0, A0, B0, polys, "ct pointwise"))) return rc;
+    if ((rc = run256_ew<0>(h, c1, A0, B1, polys, "ct pointwise"))) return rc;
+    if ((rc = run256_ew<0>(h, T, A1, B0, polys, "ct pointwise"))) return rc;
+    if ((rc = run256_ew<1>(h, c1, c1, T, polys, "ct add"))) return rc;
+    if ((rc = run256_ew<0>(h, c2, A1, B1, polys, "ct pointwise"))) return rc;
+    if ((rc = run256_transform(h, (fhe_dev::u256 *)c0, polys, false))) return rc;
+    if ((rc = run256_transform(h, (fhe_dev::u256 *)c1, polys, false))) return rc;
+    return run256_transform(h, (fhe_dev::u256 *)c2, polys, false);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// RNS engine ABI
+// ------------------------------------------------------------------------------------------------------
+extern "C" int fhe_rns_ntt_create(fhe_rns_ntt_t **out, uint32_t n, const uint64_t (*moduli)[4], uint32_t num_primes) {
+    return create_impl(out, n, moduli, num_primes);
+}
+extern "C" int fhe_rns_ntt_destroy(fhe_rns_ntt_t *h) { destroy_impl(h); return FHE_OK; }
+extern "C" int fhe_rns_ntt_set_stream(fhe_rns_ntt_t *h, void *stream) {
+    if (!h) return fail(FHE_ERR_INVALID_ARG, "null handle");
+    h->stream = stream ? (hipStream_t)stream : h->own_stream;
+    return FHE_OK;
+}
+extern "C" int fhe_rns_ntt_width_class(const fhe_rns_ntt_t *h) { return h ? h->width : fail(FHE_ERR_INVALID_ARG, "null handle"); }
+extern "C" int fhe_rns_ntt_forward(fhe_rns_ntt_t *h, void *d_data, uint32_t batch) {
+    int rc = check_call(h, batch, "forward"); if (rc) return rc;
+    if (!d_data) return fail(FHE_ERR_INVALID_ARG, "forward: null data");
+    return do_forward(h, d_data, batch);
+}
+extern "C" int fhe_rns_ntt_inverse(fhe_rns_ntt_t *h, void *d_data, uint32_t batch) {
+    int rc = check_call(h, batch, "inverse"); if (rc) return rc;
+    if (!d_data) return fail(FHE_ERR_INVALID_ARG, "inverse: null data");
+    return do_inverse(h, d_data, batch);
+}
+extern "C" int fhe_rns_ntt_pointwise(fhe_rns_ntt_t *h, void *r, const void *a, const void *b, uint32_t batch) {
+    int rc = check_call(h, batch, "pointwise"); if (rc) return rc;
+    if (!r || !a || !b) return fail(FHE_ERR_INVALID_ARG, "pointwise: null argument");
+    return do_ew<0>(h, r, a, b, batch, "pointwise");
+}
+extern "C" int fhe_rns_ntt_multiply(fhe_rns_ntt_t *h, void *r, const void *a, const void *b, uint32_t batch) {
+    int rc = check_call(h, batch, "multiply"); if (rc) return rc;
+    if (!r || !a || !b) return fail(FHE_ERR_INVALID_ARG, "multiply: null argument");
+    return do_multiply(h, r, a, b, batch);
+}
+extern "C" int fhe_rns_poly_add(fhe_rns_ntt_t *h, void *r, const void *a, const void *b, uint32_t batch) {
+    int rc = check_call(h, batch, "poly_add"); if (rc) return rc;
+    if (!r || !a || !b) return fail(FHE_ERR_INVALID_ARG, "poly_add: null argument");
+    return do_ew<1>(h, r, a, b, batch, "poly_add");
+}
+extern "C" int fhe_rns_poly_sub(fhe_rns_ntt_t *h, void *r, const void *a, const void *b, uint32_t batch) {
+    int rc = check_call(h, batch, "poly_sub"); if (rc) return rc;
+    if (!r || !a || !b) return fail(FHE_ERR_INVALID_ARG, "poly_sub: null argument");
+    return do_ew<2>(h, r, a, b, batch, "poly_sub");
+}
+extern "C" int fhe_ct_multiply(fhe_rns_ntt_t *h, void *c0, void *c1, void *c2, const void *a0, const void *a1,
+                               const void *b0, const void *b1, uint32_t batch) {
+    int rc = check_call(h, batch, "ct_multiply"); if (rc) return rc;
+    if (!c0 || !c1 || !c2 || !a0 || !a1 || !b0 || !b1) return fail(FHE_ERR_INVALID_ARG, "ct_multiply: null argument");
+    const void *ins[4] = {a0, a1, b0, b1}; void *outs[3] = {c0, c1, c2};
+    for (void *o : outs) for (const void *i : ins) if (o == i) return fail(FHE_ERR_INVALID_ARG, "ct_multiply: outputs must not alias inputs");
+    if (c0 == c1 || c0 == c2 || c1 == c2) return fail(FHE_ERR_INVALID_ARG, "ct_multiply: outputs must be distinct");
+    return do_ct_multiply(h, c0, c1, c2, a0, a1, b0, b1, batch);
+}
+extern "C" int fhe_rns_check_canonical(fhe_rns_ntt_t *h, const void *d_data, uint32_t batch) {
+    int rc = check_call(h, batch, "check_canonical"); if (rc) return rc;
+    if (!d_data) return fail(FHE_ERR_INVALID_ARG, "check_canonical: null data");
+    const uint32_t polys = batch * h->L;
+    HIP_TRY(hipMemsetAsync(h->d_flag, 0, sizeof(uint32_t), h->stream));
+    if (h->width == FHE_WIDTH_32) rc = lds_check<fhe_dev::F32>(h, d_data, polys);
+    else if (h->width == FHE_WIDTH_64) rc = lds_check<fhe_dev::F64>(h, d_data, polys);
+    else {
+        size_t count = (size_t)polys * h->n;
+        hipLaunchKernelGGL(fhe_dev::check256_kernel, dim3(ew_grid(count)), dim3(256), 0, h->stream, (const fhe_dev::u256 *)d_data,
+                           (const fhe_dev::Limb256 *)h->d_limbs, h->L, h->log_n, count, h->d_flag);
+        rc = post_launch(h->stream, "check256_kernel");
+    }
+    if (rc) return rc;
+    uint32_t flag = 0;
+    HIP_TRY(hipMemcpyAsync(&flag, h->d_flag, sizeof flag, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return flag ? fail(FHE_ERR_NONCANONICAL, "buffer holds coefficients that are not canonical residues of their limb modulus") : FHE_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// single-modulus engine ABI = RNS engine with one limb
+// ------------------------------------------------------------------------------------------------------
+extern "C" int fhe_ntt_create(fhe_ntt_t **out, uint32_t n, const uint64_t q[4]) {
+    if (!out || !q) return fail(FHE_ERR_INVALID_ARG, "null argument");
+    *out = nullptr;
+    uint64_t m[1][4]; std::memcpy(m[0], q, 32);
+    fhe_rns_ntt *impl = nullptr;
+    int rc = create_impl(&impl, n, m, 1); if (rc) return rc;
+    fhe_ntt *h = new (std::nothrow) fhe_ntt{impl};
+    if (!h) { destroy_impl(impl); return fail(FHE_ERR_INVALID_ARG, "out of host memory"); }
+    *out = h;
+    return FHE_OK;
+}
+extern "C" int fhe_ntt_destroy(fhe_ntt_t *h) { if (h) { destroy_impl(h->impl); delete h; } return FHE_OK; }
+extern "C" int fhe_ntt_set_stream(fhe_ntt_t *h, void *stream) { return h ? fhe_rns_ntt_set_stream(h->impl, stream) : fail(FHE_ERR_INVALID_ARG, "null handle"); }
+extern "C" int fhe_ntt_width_class(const fhe_ntt_t *h) { return h ? h->impl->width : fail(FHE_ERR_INVALID_ARG, "null handle"); }
+extern "C" int fhe_ntt_forward(fhe_ntt_t *h, void *d, uint32_t batch) { return h ? fhe_rns_ntt_forward(h->impl, d, batch) : fail(FHE_ERR_INVALID_ARG, "null handle"); }
+extern "C" int fhe_ntt_inverse(fhe_ntt_t *h, void *d, uint32_t batch) { return h ? fhe_rns_ntt_inverse(h->impl, d, batch) : fail(FHE_ERR_INVALID_ARG, "null handle"); }
+extern "C" int fhe_ntt_pointwise(fhe_ntt_t *h, void *r, const void *a, const void *b, uint32_t batch) {
+    return h ? fhe_rns_ntt_pointwise(h->impl, r, a, b, batch) : fail(FHE_ERR_INVALID_ARG, "null handle");
+}
+extern "C" int fhe_ntt_multiply(fhe_ntt_t *h, void *r, const void *a, const void *b, uint32_t batch) {
+    return h ? fhe_rns_ntt_multiply(h->impl, r, a, b, batch) : fail(FHE_ERR_INVALID_ARG, "null handle");
+}
+
+// ------------------------------------------------------------------------------------------------------
+// timers
+// ------------------------------------------------------------------------------------------------------
+struct fhe_timer { hipEvent_t start, stop; };
+extern "C" int fhe_timer_create(fhe_timer_t **out) {
+    if (!out) return fail(FHE_ERR_INVALID_ARG, "null argument");
+    int rc = ensure_device(); if (rc) return rc;
+    fhe_timer *t = new (std::nothrow) fhe_timer();
+    if (!t) return fail(FHE_ERR_INVALID_ARG, "out of host memory");
+    HIP_TRY(hipEventCreate(&t->start)); HIP_TRY(hipEventCreate(&t->stop));
+    *out = t;
+    return FHE_OK;
+}
+extern "C" int fhe_timer_destroy(fhe_timer_t *t) {
+    if (t) { (void)hipEventDestroy(t->start); (void)hipEventDestroy(t->stop); delete t; }
+    return FHE_OK;
+}
+extern "C" int fhe_rns_timer_start(fhe_rns_ntt_t *h, fhe_timer_t *t) {
+    if (!h || !t) return fail(FHE_ERR_INVALID_ARG, "null argument");
+    HIP_TRY(hipEventRecord(t->start, h->stream)); return FHE_OK;
+}
+extern "C" int fhe_rns_timer_stop(fhe_rns_ntt_t *h, fhe_timer_t *t) {
+    if (!h || !t) return fail(FHE_ERR_INVALID_ARG, "null argument");
+    HIP_TRY(hipEventRecord(t->stop, h->stream)); return FHE_OK;
+}
+extern "C" int fhe_timer_elapsed_ms(fhe_timer_t *t, float *ms) {
+    if (!t || !ms) return fail(FHE_ERR_INVALID_ARG, "null argument");
+    HIP_TRY(hipEventSynchronize(t->stop));
+    HIP_TRY(hipEventElapsedTime(ms, t->start, t->stop));
+    return FHE_OK;
+}

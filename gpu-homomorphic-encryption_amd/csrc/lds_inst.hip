@@ -1,0 +1,35 @@
+// lds_inst.hip -- one (field, LOGN) instance of the LDS-resident kernels.
+// Compile with -DFHE_FIELD=F32|F64 -DFHE_LOGN=11..15.
+#include "lds_launch.h"
+#include "ntt_lds.hip.h"
+
+#define CAT_(a, b, c) a##b##_##c
+#define CAT(a, b, c) CAT_(a, b, c)
+
+namespace fhe_dev {
+
+void CAT(lds_launch_, FHE_FIELD, FHE_LOGN)(const LdsArgs &A) {
+    using F = FHE_FIELD;
+    constexpr int LOGN = FHE_LOGN;
+    const dim3 grid(A.polys), block(NttCfg<LOGN>::T);
+    const Limb<F> *limbs = (const Limb<F> *)A.limbs;
+    switch (A.op) {
+        case LDS_FORWARD:
+            hipLaunchKernelGGL((ntt_forward_kernel<F, LOGN>), grid, block, 0, A.stream, (char *)A.r0, limbs, A.L);
+            break;
+        case LDS_INVERSE:
+            hipLaunchKernelGGL((ntt_inverse_kernel<F, LOGN>), grid, block, 0, A.stream, (char *)A.r0, limbs, A.L);
+            break;
+        case LDS_MULTIPLY:
+            hipLaunchKernelGGL((ntt_multiply_kernel<F, LOGN>), grid, block, 0, A.stream, (char *)A.r0, (const char *)A.a0,
+                               (const char *)A.b0, limbs, A.L);
+            break;
+        case LDS_CT_MULTIPLY:
+            hipLaunchKernelGGL((ntt_ct_multiply_kernel<F, LOGN>), grid, block, 0, A.stream, (char *)A.r0, (char *)A.r1,
+                               (char *)A.r2, (const char *)A.a0, (const char *)A.a1, (const char *)A.b0, (const char *)A.b1,
+                               limbs, A.L);
+            break;
+    }
+}
+
+}  // namespace fhe_dev

@@ -1,0 +1,25 @@
+// lds_launch.h -- host-side launch table for the LDS-resident kernels (one translation unit per
+// (field, log2 n) instance so the instances compile in parallel).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace fhe_dev {
+
+enum LdsOp { LDS_FORWARD = 0, LDS_INVERSE = 1, LDS_MULTIPLY = 2, LDS_CT_MULTIPLY = 3 };
+
+struct LdsArgs {
+    int op;
+    void *r0, *r1, *r2;                  // outputs (forward / inverse: r0 is the in-place buffer)
+    const void *a0, *a1, *b0, *b1;       // inputs
+    const void *limbs;                   // device array of Limb<F>
+    uint32_t L, polys;
+    hipStream_t stream;
+};
+
+typedef void (*lds_launch_fn)(const LdsArgs &);
+
+// width: 32 or 64.  nullptr when the instance does not exist.
+lds_launch_fn lds_lookup(int width, int log_n);
+
+}  // namespace fhe_dev

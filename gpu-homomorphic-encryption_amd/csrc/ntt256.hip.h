@@ -1,0 +1,157 @@
+// ntt256.hip.h -- FHE_WIDTH_256 kernels: full-width (q < 2^255) negacyclic NTT and element-wise ops.
+//
+// The general path behind NTTEngine / RNS_NTTEngine for moduli that do not fit the word-sized fast
+// paths (and for transform sizes outside 2^11..2^15).  It is built only from the reference's own
+// primitives (u256_dev.h: add_mod / sub_mod / mul_mod_montgomery / ct_butterfly / gs_butterfly,
+// include/bigint.cuh:27-140, include/ntt.cuh:147-167) with Montgomery-form twiddles, so data stays in
+// plain form exactly as in the reference.
+//
+// Roofline note: one 256-bit Montgomery product is ~136 v_mad_u64_u32; at ~14 integer MADs per byte of
+// compulsory traffic this path is bound by the integer multiplier, not by HBM, so it runs as plain
+// multi-pass radix-2^R register kernels over global memory (R <= 2 stages per launch, every access a
+// whole 32-byte container, consecutive lanes on consecutive containers) without LDS staging.
+#pragma once
+#include "u256_dev.h"
+
+namespace fhe_dev {
+
+struct Limb256 {
+    u256 q;
+    u256 r2;          // R^2 mod q
+    u256 ninv_m;      // n^-1 * R mod q
+    uint64_t inv0;    // -q^-1 mod 2^64  (MontgomeryParams::inv.limbs[0], include/bigint.cuh:167-173)
+    uint64_t _pad;
+    const u256 *tw_m;   // [n] psi^bitrev(k) * R mod q
+    const u256 *itw_m;  // [n] psi^-bitrev(k) * R mod q
+};
+
+// Forward pass: stages s0 .. s0+R-1 (stage s works on index bit b = log_n-1-s, m = 2^s twiddle groups).
+// grid = (ceil(n / 2^R / 256), batch*L).
+template <int R>
+__global__ void __launch_bounds__(256)
+ntt256_fwd_pass(u256 *__restrict__ data, const Limb256 *__restrict__ limbs, uint32_t L, uint32_t log_n, uint32_t s0) {
+    const uint32_t n = 1u << log_n, u = blockIdx.x * 256 + threadIdx.x;
+    if (u >= (n >> R)) return;
+    const uint32_t p = blockIdx.y;
+    const Limb256 &P = limbs[p % L];
+    const u256 q = P.q; const uint64_t inv0 = P.inv0;
+    const uint32_t b_last = log_n - s0 - R;                 // index bit of the pass's last stage
+    const uint32_t t_last = 1u << b_last;
+    const uint32_t i0 = ((u >> b_last) << (b_last + R)) | (u & (t_last - 1));
+    u256 *poly = data + (size_t)p * n;
+    u256 x[1 << R];
+#pragma unroll
+    for (int k = 0; k < (1 << R); k++) x[k] = load_u256(poly + i0 + ((uint32_t)k << b_last));
+#pragma unroll
+    for (int j = 0; j < R; j++) {
+        const uint32_t b = b_last + (R - 1 - j), m = 1u << (s0 + j);
+#pragma unroll
+        for (int hh = 0; hh < (1 << (R - 1)); hh++) {
+            const int pos = R - 1 - j;                                   // k-bit handled by this stage
+            const int k = ((hh >> pos) << (pos + 1)) | (hh & ((1 << pos) - 1));
+            const uint32_t i = i0 + ((uint32_t)k << b_last);
+            const u256 w = load_u256(P.tw_m + m + (i >> (b + 1)));
+            ct_butterfly(x[k], x[k | (1 << pos)], w, q, inv0);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < (1 << R); k++) store_u256(poly + i0 + ((uint32_t)k << b_last), x[k]);
+}
+
+// Inverse pass: index bits b0 .. b0+R-1 ascending (Gentleman-Sande); the pass that contains bit log_n-1
+// also applies the n^-1 scaling (kernels/ntt_kernels.cu:117-120).
+template <int R>
+__global__ void __launch_bounds__(256)
+ntt256_inv_pass(u256 *__restrict__ data, const Limb256 *__restrict__ limbs, uint32_t L, uint32_t log_n, uint32_t b0) {
+    const uint32_t n = 1u << log_n, u = blockIdx.x * 256 + threadIdx.x;
+    if (u >= (n >> R)) return;
+    const uint32_t p = blockIdx.y;
+    const Limb256 &P = limbs[p % L];
+    const u256 q = P.q; const uint64_t inv0 = P.inv0;
+    const uint32_t t0 = 1u << b0;
+    const uint32_t i0 = ((u >> b0) << (b0 + R)) | (u & (t0 - 1));
+    u256 *poly = data + (size_t)p * n;
+    u256 x[1 << R];
+#pragma unroll
+    for (int k = 0; k < (1 << R); k++) x[k] = load_u256(poly + i0 + ((uint32_t)k << b0));
+#pragma unroll
+    for (int j = 0; j < R; j++) {
+        const uint32_t b = b0 + j, m = n >> (b + 1);
+#pragma unroll
+        for (int hh = 0; hh < (1 << (R - 1)); hh++) {
+            const int k = ((hh >> j) << (j + 1)) | (hh & ((1 << j) - 1));
+            const uint32_t i = i0 + ((uint32_t)k << b0);
+            const u256 w = load_u256(P.itw_m + m + (i >> (b + 1)));
+            gs_butterfly(x[k], x[k | (1 << j)], w, q, inv0);
+        }
+    }
+    if (b0 + R == log_n) {
+        const u256 ninv = P.ninv_m;
+#pragma unroll
+        for (int k = 0; k < (1 << R); k++) x[k] = mont_mul(x[k], ninv, q, inv0);
+    }
+#pragma unroll
+    for (int k = 0; k < (1 << R); k++) store_u256(poly + i0 + ((uint32_t)k << b0), x[k]);
+}
+
+// Element-wise over [batch][L][n] with per-limb moduli.  OP 0: plain product a*b mod q
+// (= mont(mont(a,b), R^2)); 1: add_mod; 2: sub_mod.
+template <int OP>
+__global__ void __launch_bounds__(256)
+ew256_rns_kernel(u256 *__restrict__ r, const u256 *__restrict__ a, const u256 *__restrict__ b,
+                 const Limb256 *__restrict__ limbs, uint32_t L, uint32_t log_n, size_t count) {
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < count; g += stride) {
+        const Limb256 &P = limbs[(uint32_t)((g >> log_n) % L)];
+        u256 x = load_u256(a + g), y = load_u256(b + g), o;
+        if (OP == 0) o = mont_mul(mont_mul(x, y, P.q, P.inv0), P.r2, P.q, P.inv0);
+        else if (OP == 1) o = add_mod(x, y, P.q);
+        else o = sub_mod(x, y, P.q);
+        store_u256(r + g, o);
+    }
+}
+
+// Literal element-wise primitives with one modulus passed by value:
+// batch_mod_add_kernel / batch_mod_sub_kernel / batch_mod_mul_kernel (src/bigint.cu:171-214),
+// poly_add_kernel / poly_sub_kernel / poly_mul_scalar_kernel (src/polynomial.cu:70-111),
+// ntt_pointwise_mul_kernel (kernels/ntt_kernels.cu:124-137).
+// OP 0: mont(a,b); 1: add; 2: sub; 3: mont(a, scalar)
+template <int OP>
+__global__ void __launch_bounds__(256)
+ew256_kernel(u256 *__restrict__ r, const u256 *__restrict__ a, const u256 *__restrict__ b,
+             const u256 q, const u256 scalar, uint64_t inv0, size_t count) {
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < count; g += stride) {
+        u256 x = load_u256(a + g), o;
+        if (OP == 3) o = mont_mul(x, scalar, q, inv0);
+        else {
+            u256 y = load_u256(b + g);
+            if (OP == 0) o = mont_mul(x, y, q, inv0);
+            else if (OP == 1) o = add_mod(x, y, q);
+            else o = sub_mod(x, y, q);
+        }
+        store_u256(r + g, o);
+    }
+}
+
+__global__ void __launch_bounds__(256)
+check256_kernel(const u256 *__restrict__ a, const Limb256 *__restrict__ limbs, uint32_t L, uint32_t log_n,
+                size_t count, uint32_t *__restrict__ flag) {
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    uint32_t bad = 0;
+    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < count; g += stride) {
+        const u256 q = limbs[(uint32_t)((g >> log_n) % L)].q;
+        u256 x = load_u256(a + g), d;
+        // x >= q  <=>  x - q does not borrow
+        uint64_t borrow = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            u128_t t = (u128_t)x.l[i] - q.l[i] - borrow;
+            d.l[i] = (uint64_t)t; borrow = (uint64_t)(t >> 64) & 1;
+        }
+        bad |= (borrow == 0);
+    }
+    if (bad) atomicOr(flag, 1u);
+}
+
+}  // namespace fhe_dev

@@ -1,0 +1,441 @@
+// ntt_lds.hip.h -- LDS-resident negacyclic NTT / polymul kernels for word-sized RNS primes on gfx950.
+//   F32 : q < 2^30, 32-bit residues  (FHE_WIDTH_32, N = 2^11 .. 2^15)
+//   F64 : q < 2^62, 64-bit residues  (FHE_WIDTH_64, N = 2^11 .. 2^14)
+//
+// Replaces ntt_forward_optimized_kernel / ntt_inverse_optimized_kernel / ntt_pointwise_mul_kernel /
+// bit_reverse_kernel / ntt_forward_batch_kernel (kernels/ntt_kernels.cu:7-210) and the
+// NTTEngine::multiply launch sequence (src/ntt.cu:49-75) for word-sized moduli.
+//
+// Why a narrow path is bit-exact: with reduced operands and a prime modulus every reference
+// primitive returns the canonical residue (mont(x, w*R) = x*w mod q, add_mod, sub_mod), so any exact
+// evaluation of the same butterfly network yields the same 256-bit containers (upper words zero).
+//
+// Shape (N = 2^LOGN coefficients, one workgroup of T = N/32 threads per (polynomial, limb)):
+//   * HBM is touched exactly once per coefficient: a 4/8-byte load out of each 32-byte container
+//     (the rest rides along in the same 128-byte lines) and one full 32-byte store.
+//   * each thread owns 32 coefficients and runs 5 butterfly stages in registers (radix-32), then the
+//     workgroup transposes through LDS; log2(N) = 5 + 5 + REM stages -> 3 register groups.
+//   * LDS holds one residue per coefficient, padded by one element per 32 (phys = i + i/32) so that
+//     all access patterns below are bank-conflict-free for 64-lane wavefronts.
+//   * butterflies are Harvey lazy butterflies with Shoup twiddles (w, floor(w*2^W/q)): values live in
+//     [0,4q) (forward) / [0,2q) (inverse) and are made canonical once, before the store.
+//   * twiddles of the first register group are wave-uniform (scalar loads); the rest are vector
+//     loads from an L2-resident table shared by the whole batch.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace fhe_dev {
+
+typedef uint32_t v4u32 __attribute__((ext_vector_type(4)));   // native vectors: accepted by the nontemporal builtins
+typedef uint64_t v2u64 __attribute__((ext_vector_type(2)));
+
+// ---- field traits ---------------------------------------------------------------------------------------
+struct F32 {
+    using E = uint32_t;                 // residue
+    using TW = uint2;                   // (w, floor(w * 2^32 / q))
+    using V16 = v4u32;                  // one 16-byte half container
+    static constexpr int MAX_LOGN = 15;
+    // x*w mod q for w < q with companion ws; any x; result in [0, 2q).
+    __device__ static __forceinline__ E shoup_mul(E x, E w, E ws, E q) { return x * w - __umulhi(x, ws) * q; }
+    // a*b*2^-32 mod q, a*b < q*2^32; result in (0, 2q).
+    __device__ static __forceinline__ E mont_mul(E a, E b, E q, E qinv) {
+        uint64_t t = (uint64_t)a * b;
+        E m = (E)t * qinv;
+        return (E)(t >> 32) - __umulhi(m, q) + q;
+    }
+    __device__ static __forceinline__ E load_low(const void *container) { return __builtin_nontemporal_load((const E *)container); }
+    __device__ static __forceinline__ V16 pack(E v) { V16 o = {v, 0u, 0u, 0u}; return o; }
+    __device__ static __forceinline__ E low(const V16 &v) { return v.x; }
+    __device__ static __forceinline__ bool upper_nonzero(const V16 &v) { return (v.y | v.z | v.w) != 0; }
+    __device__ static __forceinline__ bool any_nonzero(const V16 &v) { return (v.x | v.y | v.z | v.w) != 0; }
+};
+struct F64 {
+    using E = uint64_t;
+    using TW = ulonglong2;              // (w, floor(w * 2^64 / q))
+    using V16 = v2u64;
+    static constexpr int MAX_LOGN = 14; // 2^15 x 8 B does not fit the 160 KiB LDS
+    __device__ static __forceinline__ E shoup_mul(E x, E w, E ws, E q) { return x * w - __umul64hi(x, ws) * q; }
+    __device__ static __forceinline__ E mont_mul(E a, E b, E q, E qinv) {
+        E lo = a * b, hi = __umul64hi(a, b);
+        E m = lo * qinv;
+        return hi - __umul64hi(m, q) + q;
+    }
+    __device__ static __forceinline__ E load_low(const void *container) { return __builtin_nontemporal_load((const E *)container); }
+    __device__ static __forceinline__ V16 pack(E v) { V16 o = {v, 0ull}; return o; }
+    __device__ static __forceinline__ E low(const V16 &v) { return v.x; }
+    __device__ static __forceinline__ bool upper_nonzero(const V16 &v) { return v.y != 0; }
+    __device__ static __forceinline__ bool any_nonzero(const V16 &v) { return (v.x | v.y) != 0; }
+};
+
+// Per-limb constants (device memory, one entry per RNS prime).  *_s = Shoup companion floor(x*2^W/q).
+template <class F>
+struct Limb {
+    using E = typename F::E;
+    E q, q2, qinv, _pad0;                 // qinv = q^-1 mod 2^W
+    E r1, r1_s;                           // 2^W mod q             (undo the 2^-W of mont_mul in `pointwise`)
+    E ninv, ninv_s;                       // n^-1
+    E ninvw, ninvw_s;                     // n^-1 * itw[1]
+    E ninv_r, ninv_r_s;                   // n^-1 * 2^W            (fused multiply: absorbs mont_mul's 2^-W)
+    E ninvw_r, ninvw_r_s;                 // n^-1 * itw[1] * 2^W
+    const typename F::TW *tw;             // [n] (psi^bitrev(k), shoup)
+    const typename F::TW *itw;            // [n] (psi^-bitrev(k), shoup)
+};
+using Limb32 = Limb<F32>;
+using Limb64 = Limb<F64>;
+
+// x - (x >= c ? c : 0)
+template <class E>
+__device__ __forceinline__ E csub(E x, E c) {
+    E d = x - c;
+    return d < x ? d : x;      // sub + unsigned min (d wraps above x exactly when x < c)
+}
+
+template <int LOGN>
+struct NttCfg {
+    static_assert(LOGN >= 11 && LOGN <= 15, "LDS-resident path covers 2^11 .. 2^15");
+    static constexpr int N = 1 << LOGN;
+    static constexpr int LOGT = LOGN - 5;
+    static constexpr int T = 1 << LOGT;            // threads per workgroup
+    static constexpr int REM = LOGN - 10;          // stages in the third register group (1..5)
+    static constexpr int LDS_ELEMS = N + N / 32;
+};
+
+// ---- index patterns: logical index = base(tid) | off(r), physical LDS slot = pbase(tid) + poff(r) ----
+// A : r <-> index bits [LOGT, LOGN)      (coalesced global order: consecutive lanes, consecutive coefficients)
+template <int LOGN> struct PatA {
+    using C = NttCfg<LOGN>;
+    static constexpr int BIT0 = C::LOGT;
+    static constexpr bool TW_UNIFORM = true;      // every stage on these bits has i >> (b+1) independent of tid
+    __device__ static uint32_t base(uint32_t tid) { return tid; }
+    __device__ static uint32_t pbase(uint32_t tid) { return tid + (tid >> 5); }
+    static constexpr uint32_t off(int r) { return (uint32_t)r << C::LOGT; }
+    static constexpr uint32_t poff(int r) { return (uint32_t)r * (C::T + C::T / 32); }
+};
+// M : r <-> index bits [REM, REM+5)      (forward middle group)
+template <int LOGN> struct PatM {
+    using C = NttCfg<LOGN>;
+    static constexpr int BIT0 = C::REM;
+    static constexpr bool TW_UNIFORM = false;
+    __device__ static uint32_t base(uint32_t tid) { return ((tid >> C::REM) << (C::REM + 5)) | (tid & ((1u << C::REM) - 1)); }
+    __device__ static uint32_t pbase(uint32_t tid) { uint32_t b = base(tid); return b + (b >> 5); }
+    static constexpr uint32_t off(int r) { return (uint32_t)r << C::REM; }
+    static constexpr uint32_t poff(int r) { return off(r) + (off(r) >> 5); }
+};
+// Z : r <-> index bits [0, 5)            (32 consecutive coefficients per thread)
+template <int LOGN> struct PatZ {
+    static constexpr int BIT0 = 0;
+    static constexpr bool TW_UNIFORM = false;
+    __device__ static uint32_t base(uint32_t tid) { return tid << 5; }
+    __device__ static uint32_t pbase(uint32_t tid) { return tid * 33; }
+    static constexpr uint32_t off(int r) { return (uint32_t)r; }
+    static constexpr uint32_t poff(int r) { return (uint32_t)r; }
+};
+// Y : r <-> index bits [5, 10)           (inverse middle group)
+template <int LOGN> struct PatY {
+    static constexpr int BIT0 = 5;
+    static constexpr bool TW_UNIFORM = false;
+    __device__ static uint32_t base(uint32_t tid) { return ((tid >> 5) << 10) | (tid & 31); }
+    __device__ static uint32_t pbase(uint32_t tid) { return (tid >> 5) * 1056 + (tid & 31); }
+    static constexpr uint32_t off(int r) { return (uint32_t)r << 5; }
+    static constexpr uint32_t poff(int r) { return (uint32_t)r * 33; }
+};
+
+template <class Pat, class E>
+__device__ __forceinline__ void lds_put(E *lds, uint32_t tid, const E (&x)[32]) {
+    E *p = lds + Pat::pbase(tid);
+#pragma unroll
+    for (int r = 0; r < 32; r++) p[Pat::poff(r)] = x[r];
+}
+template <class Pat, class E>
+__device__ __forceinline__ void lds_get(const E *lds, uint32_t tid, E (&x)[32]) {
+    const E *p = lds + Pat::pbase(tid);
+#pragma unroll
+    for (int r = 0; r < 32; r++) x[r] = p[Pat::poff(r)];
+}
+
+// ---- register-resident butterfly stages -------------------------------------------------------------
+// Forward (Cooley-Tukey, merged psi twiddles): stage on index bit b uses twiddle tw[m + (i >> (b+1))], m = N >> (b+1).
+// Processes r-bits KHI down to KLO of pattern Pat.  Values stay in [0, 4q).
+template <class F, int LOGN, class Pat, int KHI, int KLO>
+__device__ __forceinline__ void fwd_stages(typename F::E (&x)[32], uint32_t tid, const typename F::TW *__restrict__ tw,
+                                           typename F::E q, typename F::E q2) {
+    using E = typename F::E;
+    const uint32_t base = Pat::TW_UNIFORM ? 0u : Pat::base(tid);   // uniform -> scalar twiddle loads
+#pragma unroll
+    for (int k = KHI; k >= KLO; k--) {
+        const int b = Pat::BIT0 + k;
+        const typename F::TW *p = tw + ((1u << (LOGN - 1 - b)) + (base >> (b + 1)));
+#pragma unroll
+        for (int r = 0; r < 32; r++) {
+            if (r & (1 << k)) continue;
+            const typename F::TW w = p[Pat::off(r) >> (b + 1)];
+            E X = csub<E>(x[r], q2);
+            E Tt = F::shoup_mul(x[r | (1 << k)], w.x, w.y, q);
+            x[r] = X + Tt;
+            x[r | (1 << k)] = X - Tt + q2;
+        }
+    }
+}
+// Inverse (Gentleman-Sande): stage on index bit b uses itw[m + (i >> (b+1))].  Processes r-bits KLO up to KHI.
+// Values stay in [0, 2q).
+template <class F, int LOGN, class Pat, int KLO, int KHI>
+__device__ __forceinline__ void inv_stages(typename F::E (&x)[32], uint32_t tid, const typename F::TW *__restrict__ itw,
+                                           typename F::E q, typename F::E q2) {
+    using E = typename F::E;
+    const uint32_t base = Pat::TW_UNIFORM ? 0u : Pat::base(tid);
+#pragma unroll
+    for (int k = KLO; k <= KHI; k++) {
+        const int b = Pat::BIT0 + k;
+        const typename F::TW *p = itw + ((1u << (LOGN - 1 - b)) + (base >> (b + 1)));
+#pragma unroll
+        for (int r = 0; r < 32; r++) {
+            if (r & (1 << k)) continue;
+            const typename F::TW w = p[Pat::off(r) >> (b + 1)];
+            E X = x[r], Y = x[r | (1 << k)];
+            x[r] = csub<E>(X + Y, q2);
+            x[r | (1 << k)] = F::shoup_mul(X - Y + q2, w.x, w.y, q);
+        }
+    }
+}
+// Last inverse stage (index bit LOGN-1, single twiddle itw[1]) with the n^-1 scaling folded in.
+template <class F>
+__device__ __forceinline__ void inv_last_stage(typename F::E (&x)[32], typename F::E q, typename F::E q2, typename F::E ninv,
+                                               typename F::E ninv_s, typename F::E ninvw, typename F::E ninvw_s) {
+    using E = typename F::E;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        E X = x[r], Y = x[r | 16];
+        x[r] = F::shoup_mul(X + Y, ninv, ninv_s, q);
+        x[r | 16] = F::shoup_mul(X - Y + q2, ninvw, ninvw_s, q);
+    }
+}
+
+// ---- global memory <-> registers ----------------------------------------------------------------------
+// Coalesced gather of the low word(s) of each container, pattern A (lane stride = one 32-byte container).
+template <class F, int LOGN>
+__device__ __forceinline__ void load_A(const char *__restrict__ poly, uint32_t tid, typename F::E (&x)[32]) {
+    const char *p = poly + (size_t)tid * 32;
+#pragma unroll
+    for (int r = 0; r < 32; r++) x[r] = F::load_low(p + (size_t)r * (NttCfg<LOGN>::T * 32));
+}
+// Store the whole polynomial from LDS as full containers: consecutive lanes write consecutive 16-byte
+// halves (even lane: {value, 0...}; odd lane: zeros), i.e. 1 KiB contiguous per wave instruction.
+template <class F, int LOGN>
+__device__ __forceinline__ void store_from_lds(char *__restrict__ poly, const typename F::E *lds, uint32_t tid) {
+    using C = NttCfg<LOGN>;
+    using E = typename F::E;
+    const uint32_t half = tid & 1, c0 = tid >> 1;
+    const E *p = lds + c0 + (c0 >> 5);
+    typename F::V16 *dst = reinterpret_cast<typename F::V16 *>(poly) + tid;
+#pragma unroll 16
+    for (int s = 0; s < 64; s++) {
+        E v = p[s * (C::T / 2 + C::T / 64)];
+        typename F::V16 o = F::pack(half ? (E)0 : v);
+        __builtin_nontemporal_store(o, dst + (size_t)s * C::T);
+    }
+}
+
+// ---- whole-transform building blocks (data in registers, lds = workgroup scratch) ----------------------
+// natural-order coefficients in pattern A  ->  NTT values in pattern Z, in [0, 4q)
+template <class F, int LOGN>
+__device__ __forceinline__ void fwd_core(typename F::E (&x)[32], typename F::E *lds, uint32_t tid, const Limb<F> &P) {
+    using C = NttCfg<LOGN>;
+    fwd_stages<F, LOGN, PatA<LOGN>, 4, 0>(x, tid, P.tw, P.q, P.q2);
+    lds_put<PatA<LOGN>>(lds, tid, x);
+    __syncthreads();
+    lds_get<PatM<LOGN>>(lds, tid, x);
+    fwd_stages<F, LOGN, PatM<LOGN>, 4, 0>(x, tid, P.tw, P.q, P.q2);
+    lds_put<PatM<LOGN>>(lds, tid, x);          // same slots this thread just read: no barrier needed before
+    __syncthreads();
+    lds_get<PatZ<LOGN>>(lds, tid, x);
+    fwd_stages<F, LOGN, PatZ<LOGN>, C::REM - 1, 0>(x, tid, P.tw, P.q, P.q2);
+}
+// NTT values in pattern Z, in [0, 2q)  ->  coefficients in pattern A, in [0, 2q), scaled by the (ninv..) constants
+template <class F, int LOGN>
+__device__ __forceinline__ void inv_core(typename F::E (&x)[32], typename F::E *lds, uint32_t tid, const Limb<F> &P,
+                                         typename F::E ninv, typename F::E ninv_s, typename F::E ninvw, typename F::E ninvw_s) {
+    using C = NttCfg<LOGN>;
+    inv_stages<F, LOGN, PatZ<LOGN>, 0, 4>(x, tid, P.itw, P.q, P.q2);
+    lds_put<PatZ<LOGN>>(lds, tid, x);
+    __syncthreads();
+    lds_get<PatY<LOGN>>(lds, tid, x);
+    inv_stages<F, LOGN, PatY<LOGN>, 0, 4>(x, tid, P.itw, P.q, P.q2);
+    lds_put<PatY<LOGN>>(lds, tid, x);
+    __syncthreads();
+    lds_get<PatA<LOGN>>(lds, tid, x);
+    // index bits [10, LOGN-1) <-> r-bits [5-REM, 4) ; bit LOGN-1 <-> r-bit 4 is the scaled last stage
+    inv_stages<F, LOGN, PatA<LOGN>, 5 - C::REM, 3>(x, tid, P.itw, P.q, P.q2);
+    inv_last_stage<F>(x, P.q, P.q2, ninv, ninv_s, ninvw, ninvw_s);
+}
+
+// =========================================================================================================
+// Kernels.  grid.x = batch * L workgroups; workgroup p handles polynomial p (limb p % L).
+// =========================================================================================================
+template <class F, int LOGN>
+__global__ void __launch_bounds__(NttCfg<LOGN>::T)
+ntt_forward_kernel(char *__restrict__ data, const Limb<F> *__restrict__ limbs, uint32_t L) {
+    using C = NttCfg<LOGN>;
+    using E = typename F::E;
+    __shared__ E lds[C::LDS_ELEMS];
+    const uint32_t tid = threadIdx.x, p = blockIdx.x;
+    const Limb<F> P = limbs[p % L];
+    char *poly = data + (size_t)p * (C::N * 32);
+    E x[32];
+    load_A<F, LOGN>(poly, tid, x);
+    fwd_core<F, LOGN>(x, lds, tid, P);
+#pragma unroll
+    for (int r = 0; r < 32; r++) x[r] = csub<E>(csub<E>(x[r], P.q2), P.q);
+    lds_put<PatZ<LOGN>>(lds, tid, x);      // the slots this thread read last: no barrier needed before
+    __syncthreads();
+    store_from_lds<F, LOGN>(poly, lds, tid);
+}
+
+template <class F, int LOGN>
+__global__ void __launch_bounds__(NttCfg<LOGN>::T)
+ntt_inverse_kernel(char *__restrict__ data, const Limb<F> *__restrict__ limbs, uint32_t L) {
+    using C = NttCfg<LOGN>;
+    using E = typename F::E;
+    __shared__ E lds[C::LDS_ELEMS];
+    const uint32_t tid = threadIdx.x, p = blockIdx.x;
+    const Limb<F> P = limbs[p % L];
+    char *poly = data + (size_t)p * (C::N * 32);
+    E x[32];
+    load_A<F, LOGN>(poly, tid, x);
+    lds_put<PatA<LOGN>>(lds, tid, x);
+    __syncthreads();
+    lds_get<PatZ<LOGN>>(lds, tid, x);
+    inv_core<F, LOGN>(x, lds, tid, P, P.ninv, P.ninv_s, P.ninvw, P.ninvw_s);
+#pragma unroll
+    for (int r = 0; r < 32; r++) x[r] = csub<E>(x[r], P.q);
+    lds_put<PatA<LOGN>>(lds, tid, x);
+    __syncthreads();
+    store_from_lds<F, LOGN>(poly, lds, tid);
+}
+
+// NTTEngine::multiply in one launch: r = INTT(NTT(a) .* NTT(b)); HBM traffic = read a + read b + write r.
+template <class F, int LOGN>
+__global__ void __launch_bounds__(NttCfg<LOGN>::T)
+ntt_multiply_kernel(char *__restrict__ res, const char *__restrict__ a, const char *__restrict__ b,
+                    const Limb<F> *__restrict__ limbs, uint32_t L) {
+    using C = NttCfg<LOGN>;
+    using E = typename F::E;
+    __shared__ E lds[C::LDS_ELEMS];
+    const uint32_t tid = threadIdx.x, p = blockIdx.x;
+    const Limb<F> P = limbs[p % L];
+    const size_t off = (size_t)p * (C::N * 32);
+    E x[32], y[32];
+    load_A<F, LOGN>(a + off, tid, x);
+    load_A<F, LOGN>(b + off, tid, y);      // issued before a's butterflies: b's HBM latency hides under them
+    fwd_core<F, LOGN>(x, lds, tid, P);
+#pragma unroll
+    for (int r = 0; r < 32; r++) x[r] = csub<E>(csub<E>(x[r], P.q2), P.q);   // canonical: keeps x*y < q*2^W
+    __syncthreads();                       // all Z-pattern reads of a are done before b overwrites the slots
+    fwd_core<F, LOGN>(y, lds, tid, P);
+#pragma unroll
+    for (int r = 0; r < 32; r++) x[r] = F::mont_mul(x[r], y[r], P.q, P.qinv);   // (0,2q), carries 2^-W
+    inv_core<F, LOGN>(x, lds, tid, P, P.ninv_r, P.ninv_r_s, P.ninvw_r, P.ninvw_r_s);
+#pragma unroll
+    for (int r = 0; r < 32; r++) x[r] = csub<E>(x[r], P.q);
+    lds_put<PatA<LOGN>>(lds, tid, x);
+    __syncthreads();
+    store_from_lds<F, LOGN>(res + off, lds, tid);
+}
+
+// FHEContext::multiply tensor product in one launch (src/fhe.cu:199-218): 4 forward + 3 inverse transforms,
+// HBM traffic = read 4 polynomials + write 3.
+template <class F, int LOGN>
+__global__ void __launch_bounds__(NttCfg<LOGN>::T)
+ntt_ct_multiply_kernel(char *__restrict__ c0, char *__restrict__ c1, char *__restrict__ c2,
+                       const char *__restrict__ a0, const char *__restrict__ a1,
+                       const char *__restrict__ b0, const char *__restrict__ b1,
+                       const Limb<F> *__restrict__ limbs, uint32_t L) {
+    using C = NttCfg<LOGN>;
+    using E = typename F::E;
+    __shared__ E lds[C::LDS_ELEMS];
+    const uint32_t tid = threadIdx.x, p = blockIdx.x;
+    const Limb<F> P = limbs[p % L];
+    const size_t off = (size_t)p * (C::N * 32);
+    E A0[32], A1[32], B0[32], B1[32];
+    load_A<F, LOGN>(a0 + off, tid, A0);
+    load_A<F, LOGN>(a1 + off, tid, A1);
+    fwd_core<F, LOGN>(A0, lds, tid, P);
+    load_A<F, LOGN>(b0 + off, tid, B0);
+    __syncthreads();
+    fwd_core<F, LOGN>(A1, lds, tid, P);
+    load_A<F, LOGN>(b1 + off, tid, B1);
+    __syncthreads();
+    fwd_core<F, LOGN>(B0, lds, tid, P);
+    __syncthreads();
+    fwd_core<F, LOGN>(B1, lds, tid, P);
+#pragma unroll
+    for (int r = 0; r < 32; r++) {
+        E u0 = csub<E>(csub<E>(A0[r], P.q2), P.q), u1 = csub<E>(csub<E>(A1[r], P.q2), P.q);   // canonical a-side
+        E v0 = B0[r], v1 = B1[r];                                                             // lazy b-side (< 4q)
+        E t00 = F::mont_mul(u0, v0, P.q, P.qinv);
+        E t01 = F::mont_mul(u0, v1, P.q, P.qinv);
+        E t10 = F::mont_mul(u1, v0, P.q, P.qinv);
+        E t11 = F::mont_mul(u1, v1, P.q, P.qinv);
+        A0[r] = t00;                           // (0,2q)
+        A1[r] = csub<E>(t01 + t10, P.q2);      // (0,4q) -> [0,2q)
+        B0[r] = t11;
+    }
+    inv_core<F, LOGN>(A0, lds, tid, P, P.ninv_r, P.ninv_r_s, P.ninvw_r, P.ninvw_r_s);
+#pragma unroll
+    for (int r = 0; r < 32; r++) A0[r] = csub<E>(A0[r], P.q);
+    lds_put<PatA<LOGN>>(lds, tid, A0);
+    __syncthreads();
+    store_from_lds<F, LOGN>(c0 + off, lds, tid);
+    __syncthreads();
+    inv_core<F, LOGN>(A1, lds, tid, P, P.ninv_r, P.ninv_r_s, P.ninvw_r, P.ninvw_r_s);
+#pragma unroll
+    for (int r = 0; r < 32; r++) A1[r] = csub<E>(A1[r], P.q);
+    lds_put<PatA<LOGN>>(lds, tid, A1);
+    __syncthreads();
+    store_from_lds<F, LOGN>(c1 + off, lds, tid);
+    __syncthreads();
+    inv_core<F, LOGN>(B0, lds, tid, P, P.ninv_r, P.ninv_r_s, P.ninvw_r, P.ninvw_r_s);
+#pragma unroll
+    for (int r = 0; r < 32; r++) B0[r] = csub<E>(B0[r], P.q);
+    lds_put<PatA<LOGN>>(lds, tid, B0);
+    __syncthreads();
+    store_from_lds<F, LOGN>(c2 + off, lds, tid);
+}
+
+// Element-wise kernels over [batch][L][n] containers of word-sized residues: one 16-byte half-container per lane.
+// op 0: r = a*b mod q (plain product in the NTT domain); 1: a+b; 2: a-b.
+template <class F, int OP>
+__global__ void __launch_bounds__(256)
+ew_kernel(typename F::V16 *__restrict__ r, const typename F::V16 *__restrict__ a, const typename F::V16 *__restrict__ b,
+          const Limb<F> *__restrict__ limbs, uint32_t L, uint32_t log_n, size_t halves) {
+    using E = typename F::E;
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < halves; g += stride) {
+        E o = 0;
+        if (!(g & 1)) {
+            const Limb<F> &P = limbs[(uint32_t)((g >> (log_n + 1)) % L)];
+            E x = F::load_low(a + g), y = F::load_low(b + g), q = P.q;
+            if (OP == 0) o = csub<E>(F::shoup_mul(F::mont_mul(x, y, q, P.qinv), P.r1, P.r1_s, q), q);
+            else if (OP == 1) o = csub<E>(x + y, q);
+            else o = csub<E>(x - y + q, q);
+        }
+        __builtin_nontemporal_store(F::pack(o), r + g);
+    }
+}
+
+// Canonical-input scan: flags any container whose value is >= q or whose upper words are not zero.
+template <class F>
+__global__ void __launch_bounds__(256)
+check_kernel(const typename F::V16 *__restrict__ a, const Limb<F> *__restrict__ limbs, uint32_t L, uint32_t log_n,
+             size_t halves, uint32_t *__restrict__ flag) {
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    bool bad = false;
+    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < halves; g += stride) {
+        typename F::V16 v = a[g];
+        if (g & 1) bad |= F::any_nonzero(v);
+        else bad |= F::upper_nonzero(v) || F::low(v) >= limbs[(uint32_t)((g >> (log_n + 1)) % L)].q;
+    }
+    if (bad) atomicOr(flag, 1u);
+}
+
+}  // namespace fhe_dev

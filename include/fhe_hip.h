@@ -1,0 +1,154 @@
+/*
+ * fhe_hip.h -- C ABI of the MI355X (gfx950) RNS-NTT polynomial-multiply engine.
+ *
+ * This is the drop-in boundary for the reference's hot path.  The reference
+ * (codebasecomprehension987/gpu-homomorphic-encryption) has no FFI layer of its own: its boundary is
+ * the C++ class surface fhe::NTTEngine / RNS_NTTEngine / PolynomialOps / FHEContext::multiply.
+ * Every entry point below names the reference interface it replaces (file:line, relative to the
+ * reference root).  The C++ mirror of those classes lives in include/fhe/ and is a header-only
+ * wrapper over this ABI; INTEGRATION.md shows the binding a maintainer adds on the reference side.
+ *
+ * Conventions
+ *   - 256-bit values are the reference's `uint256_t` (include/bigint.cuh:9-11): 4 x uint64_t,
+ *     little-endian limbs, 32 bytes, 8-byte aligned.  Host-side moduli are passed as `const uint64_t[4]`.
+ *   - `d_*` arguments are raw DEVICE pointers owned by the caller (hipMalloc / fhe_hip_malloc /
+ *     torch tensor storage), exactly as the reference takes cudaMalloc'd pointers (src/ntt.cu:30-75).
+ *   - Polynomial data is limb-major `[batch][L][n]` containers (src/ntt.cu:161).
+ *   - Coefficients handed to the NTT entry points must be canonical residues (< q_limb).
+ *   - Work is enqueued on the handle's stream and NOT synchronised (callers sync, as the
+ *     reference's callers do: tests/test_fhe.cu:88,97,155), unless env FHE_HIP_SYNC=1.
+ *   - Every function returns 0 on success or a negative fhe_status; fhe_hip_last_error() gives the
+ *     message of the calling thread's last failure.  (The reference reports no errors at all.)
+ *   - A handle is bound to the device that was current at creation and is not thread-safe; distinct
+ *     handles may be used from distinct threads (docs/API_REFERENCE.md:600-606).
+ *   - There is NO CPU fallback: without a usable HIP device every compute entry point fails with
+ *     FHE_ERR_NO_DEVICE.
+ */
+#ifndef FHE_HIP_H
+#define FHE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FHE_HIP_ABI_VERSION 1
+
+typedef enum fhe_status {
+    FHE_OK = 0,
+    FHE_ERR_INVALID_ARG = -1,   /* null pointer, n not a power of two, batch == 0 ... */
+    FHE_ERR_BAD_MODULUS = -2,   /* even, >= 2^255, not prime, or q != 1 (mod 2n) */
+    FHE_ERR_NO_DEVICE = -3,     /* no HIP device / HIP runtime failure at init */
+    FHE_ERR_HIP = -4,           /* a HIP call failed; message holds hipGetErrorString */
+    FHE_ERR_UNSUPPORTED = -5,   /* size outside what the kernels were built for */
+    FHE_ERR_NONCANONICAL = -6   /* fhe_*_check found coefficients >= q in a fast-path buffer */
+} fhe_status;
+
+/* Which kernel family a modulus set selected (reported, never chosen by the caller). */
+typedef enum fhe_width_class {
+    FHE_WIDTH_32 = 1,    /* every q < 2^30 : 32-bit lazy Shoup butterflies, whole NTT in LDS */
+    FHE_WIDTH_64 = 2,    /* every q < 2^62 : 64-bit lazy butterflies, whole NTT in LDS */
+    FHE_WIDTH_256 = 4    /* anything else < 2^255 : full 4x64-bit Montgomery (R = 2^256), multi-pass */
+} fhe_width_class;
+
+typedef struct fhe_ntt fhe_ntt_t;          /* replaces fhe::NTTEngine      (include/ntt.cuh:72-103)  */
+typedef struct fhe_rns_ntt fhe_rns_ntt_t;  /* replaces fhe::RNS_NTTEngine  (include/ntt.cuh:106-137) */
+
+/* ---- library / device plumbing (the reference calls the CUDA runtime directly) ------------- */
+int fhe_hip_abi_version(void);
+const char *fhe_hip_last_error(void);
+int fhe_hip_device_count(int *count);
+int fhe_hip_set_device(int device);
+int fhe_hip_get_device(int *device);
+int fhe_hip_device_name(char *buf, size_t buflen);            /* gcnArchName + marketing name */
+int fhe_hip_malloc(void **d_ptr, size_t bytes);               /* cudaMalloc   (src/polynomial.cpp analogue: src/polynomial.cu:8) */
+int fhe_hip_free(void *d_ptr);                                /* cudaFree     (src/polynomial.cu:13) */
+int fhe_hip_memset(void *d_ptr, int value, size_t bytes);     /* cudaMemset   (src/polynomial.cu:9) */
+int fhe_hip_memcpy_h2d(void *d_dst, const void *h_src, size_t bytes);
+int fhe_hip_memcpy_d2h(void *h_dst, const void *d_src, size_t bytes);
+int fhe_hip_memcpy_d2d(void *d_dst, const void *d_src, size_t bytes);
+int fhe_hip_sync(void);                                       /* cudaDeviceSynchronize (tests/test_fhe.cu:88) */
+
+/* ---- host-side parameter maths ------------------------------------------------------------ */
+/* compute_montgomery_inverse (src/bigint.cu:23-40): inv[0] = -q^-1 mod 2^64 by 6 Newton steps,
+ * inv[1..3] = 0.  Literal, including the deterministic garbage for even q. */
+int fhe_montgomery_inverse(const uint64_t q[4], uint64_t inv[4]);
+/* compute_montgomery_params (src/bigint.cu:42-55) with r_squared actually computed. */
+int fhe_montgomery_params(const uint64_t q[4], uint64_t r_squared[4], uint64_t inv[4]);
+/* find_ntt_prime / generate_rns_primes (include/rns.cuh:139-149; src/rns.cu:183-209 are stubs):
+ * the `count` smallest primes >= 2^(bits-1) with q = 1 (mod 2n); bits <= 64. */
+int fhe_find_ntt_primes(uint32_t bits, uint32_t n, uint32_t count, uint64_t *primes_out);
+/* find_primitive_root (src/ntt.cu:110-114 is a stub): primitive 2n-th root of unity psi, chosen as
+ * the first x^((q-1)/2n), x = 2,3,..., whose n-th power is q-1. */
+int fhe_find_psi(uint32_t n, const uint64_t q[4], uint64_t psi[4]);
+
+/* ---- element-wise 256-bit modular kernels, literal reference semantics ---------------------- */
+/* batch_mod_add_kernel (src/bigint.cu:171-184) / poly_add_kernel (src/polynomial.cu:70-82):
+ * r[i] = add_mod(a[i], b[i], q)  (include/bigint.cuh:27-48).  stream may be NULL (default stream). */
+int fhe_u256_add_mod(void *d_r, const void *d_a, const void *d_b, const uint64_t q[4], size_t count, void *stream);
+/* batch_mod_sub_kernel (src/bigint.cu:186-199) / poly_sub_kernel (src/polynomial.cu:84-96). */
+int fhe_u256_sub_mod(void *d_r, const void *d_a, const void *d_b, const uint64_t q[4], size_t count, void *stream);
+/* batch_mod_mul_kernel (src/bigint.cu:201-214) / ntt_pointwise_mul_kernel (kernels/ntt_kernels.cu:124-137):
+ * r[i] = mul_mod_montgomery(a[i], b[i], q, inv)  (include/bigint.cuh:76-140); only inv0 = inv.limbs[0] is used. */
+int fhe_u256_mont_mul(void *d_r, const void *d_a, const void *d_b, const uint64_t q[4], uint64_t inv0, size_t count, void *stream);
+/* poly_mul_scalar_kernel (src/polynomial.cu:98-111): r[i] = mul_mod_montgomery(a[i], scalar, q, inv). */
+int fhe_u256_mont_mul_scalar(void *d_r, const void *d_a, const uint64_t scalar[4], const uint64_t q[4], uint64_t inv0, size_t count, void *stream);
+
+/* ---- single-modulus engine: fhe::NTTEngine -------------------------------------------------- */
+/* NTTEngine::NTTEngine(n, modulus) (src/ntt.cu:7-22) + precompute_twiddle_factors (:77-107), with the
+ * root / inverse / table placeholders replaced by real values.  q prime, q = 1 (mod 2n), q < 2^255,
+ * 8 <= n <= 65536 a power of two. */
+int fhe_ntt_create(fhe_ntt_t **out, uint32_t n, const uint64_t q[4]);
+int fhe_ntt_destroy(fhe_ntt_t *h);                                            /* ~NTTEngine (src/ntt.cu:24-28) */
+int fhe_ntt_set_stream(fhe_ntt_t *h, void *stream);   /* adopt a caller stream (e.g. torch's); NULL = back to the private one */
+int fhe_ntt_width_class(const fhe_ntt_t *h);
+/* NTTEngine::forward (src/ntt.cu:30-40) / forward_batch (include/ntt.cuh:87): in place, `batch`
+ * polynomials contiguous [batch][n]; natural order in, merged-CT (bit-reversed) order out. */
+int fhe_ntt_forward(fhe_ntt_t *h, void *d_data, uint32_t batch);
+/* NTTEngine::inverse (src/ntt.cu:42-47) / inverse_batch (include/ntt.cuh:88): exact inverse of
+ * forward including the n^-1 scaling (kernels/ntt_kernels.cu:117-120). */
+int fhe_ntt_inverse(fhe_ntt_t *h, void *d_data, uint32_t batch);
+/* ntt_pointwise_mul_kernel's intent (kernels/ntt_kernels.cu:124-137): r = a .* b mod q, plain product. */
+int fhe_ntt_pointwise(fhe_ntt_t *h, void *d_r, const void *d_a, const void *d_b, uint32_t batch);
+/* NTTEngine::multiply (src/ntt.cu:49-75): r = a (*) b mod (x^n + 1, q); d_a, d_b are not modified;
+ * d_r may alias neither.  One fused launch on the 32/64-bit paths. */
+int fhe_ntt_multiply(fhe_ntt_t *h, void *d_r, const void *d_a, const void *d_b, uint32_t batch);
+
+/* ---- RNS engine: fhe::RNS_NTTEngine ---------------------------------------------------------- */
+/* RNS_NTTEngine::RNS_NTTEngine(n, rns_moduli, num_primes) (src/ntt.cu:122-145): moduli are copied. */
+int fhe_rns_ntt_create(fhe_rns_ntt_t **out, uint32_t n, const uint64_t (*moduli)[4], uint32_t num_primes);
+int fhe_rns_ntt_destroy(fhe_rns_ntt_t *h);                                    /* src/ntt.cu:147-156 */
+int fhe_rns_ntt_set_stream(fhe_rns_ntt_t *h, void *stream);
+int fhe_rns_ntt_width_class(const fhe_rns_ntt_t *h);
+/* forward_rns / inverse_rns (src/ntt.cu:158-171): data [batch][L][n]; one launch for all limbs. */
+int fhe_rns_ntt_forward(fhe_rns_ntt_t *h, void *d_data, uint32_t batch);
+int fhe_rns_ntt_inverse(fhe_rns_ntt_t *h, void *d_data, uint32_t batch);
+int fhe_rns_ntt_pointwise(fhe_rns_ntt_t *h, void *d_r, const void *d_a, const void *d_b, uint32_t batch);
+/* multiply_rns (include/ntt.cuh:124-126; declared, never defined in the reference). */
+int fhe_rns_ntt_multiply(fhe_rns_ntt_t *h, void *d_r, const void *d_a, const void *d_b, uint32_t batch);
+/* PolynomialOps::add / sub over RNS polynomials (src/polynomial.cu:36-52), per-limb moduli. */
+int fhe_rns_poly_add(fhe_rns_ntt_t *h, void *d_r, const void *d_a, const void *d_b, uint32_t batch);
+int fhe_rns_poly_sub(fhe_rns_ntt_t *h, void *d_r, const void *d_a, const void *d_b, uint32_t batch);
+/* FHEContext::multiply tensor product (src/fhe.cu:199-218), relinearisation excluded (:220 is a stub):
+ * c0 = a0*b0, c1 = a0*b1 + a1*b0, c2 = a1*b1.  4 forward + 3 inverse transforms instead of the
+ * reference's 8 + 4 (results identical: modular arithmetic is exact). */
+int fhe_ct_multiply(fhe_rns_ntt_t *h, void *d_c0, void *d_c1, void *d_c2,
+                    const void *d_a0, const void *d_a1, const void *d_b0, const void *d_b1, uint32_t batch);
+/* Scan a [batch][L][n] buffer for coefficients that are not canonical (>= q_limb, or non-zero
+ * upper limbs on the narrow paths).  Synchronises.  FHE_OK or FHE_ERR_NONCANONICAL. */
+int fhe_rns_check_canonical(fhe_rns_ntt_t *h, const void *d_data, uint32_t batch);
+
+/* ---- timing on the handle's stream (hipEvent pair; what bench.py uses for the roofline) ------ */
+typedef struct fhe_timer fhe_timer_t;
+int fhe_timer_create(fhe_timer_t **out);
+int fhe_timer_destroy(fhe_timer_t *t);
+int fhe_rns_timer_start(fhe_rns_ntt_t *h, fhe_timer_t *t);   /* hipEventRecord(start, h->stream) */
+int fhe_rns_timer_stop(fhe_rns_ntt_t *h, fhe_timer_t *t);    /* hipEventRecord(stop,  h->stream) */
+int fhe_timer_elapsed_ms(fhe_timer_t *t, float *ms);         /* synchronises on stop */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FHE_HIP_H */

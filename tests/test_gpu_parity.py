@@ -1,0 +1,267 @@
+"""GPU parity: the HIP engine, called through the C ABI (ctypes), against the CPU oracle on the same
+seeded inputs.  Integer work: every comparison is bit-exact on whole arrays."""
+import os
+import random
+
+import numpy as np
+import pytest
+
+import ntt_math as nm
+from workload import rns_poly
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng(pkg):
+    if pkg.device_count() < 1:
+        pytest.fail("no HIP device visible: the gpu-marked tests must run on the MI355X box")
+    return pkg
+
+
+def _up(pkg, arr):
+    return pkg.DeviceBuffer.from_numpy(arr)
+
+
+# ------------------------------------------------------------------------------------ L0 primitives
+def _l0_moduli():
+    rng = random.Random(4321)
+    ms = [100000, 12289, 40961, (1 << 39) + 1, 1 << 60]
+    ms += nm.ntt_primes(30, 8192, 1) + nm.ntt_primes(60, 8192, 1)
+    for bits in (64, 65, 128, 129, 192, 254, 255):
+        ms.append(rng.getrandbits(bits) | (1 << (bits - 1)) | 1)
+    return ms
+
+
+def test_elementwise_primitives_literal(eng, oracle):
+    """batch_mod_{add,sub,mul}_kernel semantics incl. unreduced operands and the even modulus 2^60."""
+    rng = random.Random(11)
+    for q in _l0_moduli():
+        edge = [0, 1, q - 1, q, q + 1, (1 << 256) - 1, 1 << 255, 12345, 67890]
+        pairs = [(a, b) for a in edge for b in edge]
+        pairs += [(rng.randrange(q), rng.randrange(q)) for _ in range(3000)]
+        pairs += [(rng.getrandbits(256), rng.getrandbits(256)) for _ in range(500)]
+        A = oracle.to_limbs([a for a, _ in pairs]); B = oracle.to_limbs([b for _, b in pairs])
+        dA, dB = _up(eng, A), _up(eng, B)
+        dR = eng.DeviceBuffer(A.nbytes)
+        inv0 = eng.montgomery_inverse(q) & ((1 << 64) - 1)
+        assert inv0 == oracle.mont_inverse(q)
+        eng.u256_add_mod(dR, dA, dB, q, len(pairs)); assert np.array_equal(dR.download(), oracle.batch_add(A, B, q))
+        eng.u256_sub_mod(dR, dA, dB, q, len(pairs)); assert np.array_equal(dR.download(), oracle.batch_sub(A, B, q))
+        eng.u256_mont_mul(dR, dA, dB, q, inv0, len(pairs)); assert np.array_equal(dR.download(), oracle.batch_mont(A, B, q, inv0))
+        s = rng.randrange(q)
+        S = oracle.to_limbs([s] * len(pairs))
+        eng.u256_mont_mul_scalar(dR, dA, s, q, inv0, len(pairs))
+        assert np.array_equal(dR.download(), oracle.batch_mont(A, S, q, inv0))
+
+
+def test_reference_test_known_answers_on_device(eng, oracle):
+    """tests/test_fhe.cu:24-63: 12345 +/- 67890 mod 100000 through the device kernels."""
+    A, B = oracle.to_limbs([12345]), oracle.to_limbs([67890])
+    dA, dB, dR = _up(eng, A), _up(eng, B), eng.DeviceBuffer(32)
+    eng.u256_add_mod(dR, dA, dB, 100000, 1); assert oracle.from_limbs(dR.download()) == [80235]
+    eng.u256_sub_mod(dR, dA, dB, 100000, 1); assert oracle.from_limbs(dR.download()) == [44455]
+
+
+# ------------------------------------------------------------------------------------ transforms
+CASES = [
+    # (n, moduli spec, batch, expected width class)
+    (1024, [12289], 2, 4),                      # the reference's test_ntt_transform shape -> general path
+    (64, ("bits", 250, 2), 2, 4),
+    (4096, ("bits", 250, 1), 1, 4),
+    (2048, [40961], 3, 1),                      # test_polynomial_multiplication shape -> 32-bit LDS path
+    (4096, ("bits", 30, 2), 2, 1),
+    (8192, ("bits", 30, 4), 3, 1),              # BASELINE config 2 shape
+    (16384, ("bits", 30, 3), 2, 1),
+    (32768, ("bits", 30, 1), 2, 1),
+    (2048, ("bits", 60, 2), 2, 2),
+    (8192, ("bits", 60, 2), 2, 2),
+    (16384, ("bits", 40, 6), 1, 2),             # BASELINE config 4 shape (40-bit primes)
+    (8192, ("bits", 64, 1), 1, 4),              # 64-bit prime: too wide for the lazy 64-bit path
+    (65536, ("bits", 30, 1), 1, 4),             # larger than LDS: general path
+]
+
+
+def _moduli(spec, n):
+    if isinstance(spec, tuple):
+        return nm.ntt_primes(spec[1], n, spec[2])
+    return list(spec)
+
+
+@pytest.mark.parametrize("n,spec,batch,width", CASES)
+def test_forward_inverse_multiply_match_oracle(eng, oracle, n, spec, batch, width):
+    moduli = _moduli(spec, n)
+    L = len(moduli)
+    e = eng.RnsNttEngine(n, moduli)
+    assert e.width_class == width
+    rp = oracle.RnsPlan(n, moduli)
+    a = rns_poly(1, moduli, n, batch); b = rns_poly(2, moduli, n, batch)
+    dA, dB = _up(eng, a), _up(eng, b)
+    dR = eng.DeviceBuffer(a.nbytes)
+    shape = a.shape
+    # forward
+    e.forward(dA, batch)
+    fa = dA.download(shape)
+    want_fa = rp.forward(a, threads=8)
+    assert np.array_equal(fa, want_fa)
+    # inverse returns the input
+    e.inverse(dA, batch)
+    assert np.array_equal(dA.download(shape), a)
+    # inverse of arbitrary NTT-domain data
+    dT = _up(eng, b); e.inverse(dT, batch)
+    assert np.array_equal(dT.download(shape), rp.inverse(b, threads=8))
+    # pointwise (plain product)
+    e.pointwise(dR, dA, dB, batch)
+    want_pw = np.stack([np.stack([rp.plans[l].pointwise(np.ascontiguousarray(a[bi, l]), np.ascontiguousarray(b[bi, l]))
+                                  for l in range(L)]) for bi in range(batch)])
+    assert np.array_equal(dR.download(shape), want_pw)
+    # multiply: operands preserved, result == oracle polymul
+    e.multiply(dR, dA, dB, batch)
+    assert np.array_equal(dR.download(shape), rp.polymul(a, b, threads=8))
+    assert np.array_equal(dA.download(shape), a) and np.array_equal(dB.download(shape), b)
+    # add / sub
+    e.poly_add(dR, dA, dB, batch)
+    want = np.stack([np.stack([oracle.batch_add(np.ascontiguousarray(a[bi, l]), np.ascontiguousarray(b[bi, l]), moduli[l])
+                               for l in range(L)]) for bi in range(batch)])
+    assert np.array_equal(dR.download(shape), want)
+    e.poly_sub(dR, dA, dB, batch)
+    want = np.stack([np.stack([oracle.batch_sub(np.ascontiguousarray(a[bi, l]), np.ascontiguousarray(b[bi, l]), moduli[l])
+                               for l in range(L)]) for bi in range(batch)])
+    assert np.array_equal(dR.download(shape), want)
+    e.check_canonical(dR, batch)
+
+
+@pytest.mark.parametrize("n,spec,batch", [(2048, [40961], 2), (8192, ("bits", 30, 4), 2), (4096, ("bits", 60, 2), 1),
+                                          (256, ("bits", 250, 2), 1)])
+def test_ct_multiply_matches_oracle(eng, oracle, n, spec, batch):
+    """FHEContext::multiply tensor product (src/fhe.cu:199-218)."""
+    moduli = _moduli(spec, n)
+    e = eng.RnsNttEngine(n, moduli); rp = oracle.RnsPlan(n, moduli)
+    a0, a1, b0, b1 = (rns_poly(s, moduli, n, batch) for s in (3, 4, 5, 6))
+    d = [_up(eng, x) for x in (a0, a1, b0, b1)]
+    c = [eng.DeviceBuffer(a0.nbytes) for _ in range(3)]
+    e.ct_multiply(c[0], c[1], c[2], d[0], d[1], d[2], d[3], batch)
+    w0, w1, w2 = rp.ct_multiply(a0, a1, b0, b1, threads=8)
+    assert np.array_equal(c[0].download(a0.shape), w0)
+    assert np.array_equal(c[1].download(a0.shape), w1)
+    assert np.array_equal(c[2].download(a0.shape), w2)
+    for buf, src in zip(d, (a0, a1, b0, b1)):
+        assert np.array_equal(buf.download(a0.shape), src)
+
+
+def test_single_modulus_engine_reference_scenarios(eng, oracle):
+    """tests/test_fhe.cu:65-167 through the NTTEngine-shaped ABI, asserting instead of printing."""
+    # test_ntt_transform: N = 1024, q = 12289, data i+1, forward then inverse
+    e = eng.NttEngine(1024, 12289)
+    x = oracle.to_limbs(range(1, 1025)); d = _up(eng, x)
+    e.forward(d); y = d.download()
+    assert np.array_equal(y, oracle.Plan(1024, 12289).forward(x)) and not np.array_equal(y, x)
+    e.inverse(d); assert np.array_equal(d.download(), x)
+    # test_polynomial_multiplication: N = 2048, q = 40961, coefficients < 100
+    rng = random.Random(5)
+    a = oracle.to_limbs(rng.randrange(100) for _ in range(2048)); b = oracle.to_limbs(rng.randrange(100) for _ in range(2048))
+    e2 = eng.NttEngine(2048, 40961)
+    dA, dB, dR = _up(eng, a), _up(eng, b), eng.DeviceBuffer(a.nbytes)
+    e2.multiply(dR, dA, dB)
+    p = oracle.Plan(2048, 40961)
+    assert np.array_equal(dR.download(), p.schoolbook(a, b))
+
+
+# ------------------------------------------------------------------------------------ edge cases
+def test_edge_polynomials(eng, oracle):
+    n = 8192; moduli = nm.ntt_primes(30, n, 2); L = 2
+    e = eng.RnsNttEngine(n, moduli); rp = oracle.RnsPlan(n, moduli)
+    zero = np.zeros((1, L, n, 4), np.uint64)
+    one = zero.copy(); one[:, :, 0, 0] = 1
+    top = zero.copy()
+    for l, q in enumerate(moduli):
+        top[0, l, :, 0] = q - 1
+    xn1 = zero.copy(); xn1[:, :, n - 1, 0] = 1             # x^(n-1)
+    r = rns_poly(9, moduli, n, 1)
+    dR = eng.DeviceBuffer(zero.nbytes)
+    for a, b in ((zero, r), (one, r), (top, top), (xn1, xn1), (xn1, r)):
+        e.multiply(dR, _up(eng, a), _up(eng, b), 1)
+        assert np.array_equal(dR.download(zero.shape), rp.polymul(a, b))
+    # x^(n-1) * x^(n-1) = x^(2n-2) = -x^(n-2)
+    got = dR  # last result is xn1 * r; recompute the monomial square explicitly
+    e.multiply(dR, _up(eng, xn1), _up(eng, xn1), 1)
+    res = dR.download(zero.shape)
+    for l, q in enumerate(moduli):
+        assert int(res[0, l, n - 2, 0]) == q - 1 and int(res[0, l].sum()) == q - 1
+
+
+def test_noncanonical_input_is_detected(eng):
+    n = 2048; moduli = [40961]
+    e = eng.RnsNttEngine(n, moduli)
+    x = np.zeros((1, 1, n, 4), np.uint64); x[0, 0, 5, 0] = 40961
+    with pytest.raises(eng.FheError) as ei:
+        e.check_canonical(_up(eng, x), 1)
+    assert ei.value.code == -6
+    x[0, 0, 5, 0] = 3; x[0, 0, 7, 2] = 1
+    with pytest.raises(eng.FheError):
+        e.check_canonical(_up(eng, x), 1)
+    x[0, 0, 7, 2] = 0
+    e.check_canonical(_up(eng, x), 1)
+
+
+def test_error_reporting(eng):
+    with pytest.raises(eng.FheError) as ei:
+        eng.RnsNttEngine(8192, [12289])            # 12289 != 1 mod 16384
+    assert ei.value.code == -2
+    with pytest.raises(eng.FheError) as ei:
+        eng.RnsNttEngine(1000, [12289])
+    assert ei.value.code == -1
+    e = eng.RnsNttEngine(2048, [40961])
+    buf = eng.DeviceBuffer(2048 * 32)
+    with pytest.raises(eng.FheError):
+        e.multiply(buf, buf, buf, 1)               # aliasing
+    with pytest.raises(eng.FheError):
+        e.forward(buf, 0)                          # empty batch
+
+
+# ------------------------------------------------------------------------------------ full-size properties
+def test_full_size_properties_config2(eng, oracle):
+    """BASELINE config 2 at bench scale (N = 8192, 4 limbs, batch 256): size-independent properties +
+    oracle spot checks on sampled polynomials."""
+    n, L, batch = 8192, 4, 256
+    moduli = nm.ntt_primes(30, n, L)
+    e = eng.RnsNttEngine(n, moduli); rp = oracle.RnsPlan(n, moduli)
+    a = rns_poly(21, moduli, n, batch); b = rns_poly(22, moduli, n, batch)
+    dA, dB = _up(eng, a), _up(eng, b)
+    dR, dS = eng.DeviceBuffer(a.nbytes), eng.DeviceBuffer(a.nbytes)
+    # round trip
+    e.forward(dA, batch); e.inverse(dA, batch)
+    assert np.array_equal(dA.download(a.shape), a)
+    # commutativity and distributivity: a*(b+a) == a*b + a*a
+    e.multiply(dR, dA, dB, batch); ab = dR.download(a.shape)
+    e.multiply(dR, dB, dA, batch); assert np.array_equal(dR.download(a.shape), ab)
+    e.poly_add(dS, dA, dB, batch); e.multiply(dR, dA, dS, batch); lhs = dR.download(a.shape)
+    e.multiply(dS, dA, dA, batch); dAB = _up(eng, ab); e.poly_add(dR, dAB, dS, batch)
+    assert np.array_equal(dR.download(a.shape), lhs)
+    # fused multiply == forward, pointwise, inverse
+    dFa, dFb = _up(eng, a), _up(eng, b)
+    e.forward(dFa, batch); e.forward(dFb, batch); e.pointwise(dR, dFa, dFb, batch); e.inverse(dR, batch)
+    assert np.array_equal(dR.download(a.shape), ab)
+    # oracle on a sample of the batch
+    for bi in (0, 97, 255):
+        want = rp.polymul(np.ascontiguousarray(a[bi:bi + 1]), np.ascontiguousarray(b[bi:bi + 1]), threads=8)
+        assert np.array_equal(ab[bi:bi + 1], want)
+    e.check_canonical(dR, batch)
+
+
+def test_golden_digests_on_device(eng, oracle, golden_dir):
+    """Committed digests (tests/golden/l2_digests.json, made by tests/golden/make_golden.py from the oracle)."""
+    import hashlib, json
+    with open(os.path.join(golden_dir, "l2_digests.json")) as f:
+        G = json.load(f)
+    for c in G["cases"]:
+        n, moduli, batch = c["n"], [int(q) for q in c["moduli"]], c["batch"]
+        e = eng.RnsNttEngine(n, moduli)
+        a = rns_poly(c["seed_a"], moduli, n, batch); b = rns_poly(c["seed_b"], moduli, n, batch)
+        dA, dB, dR = _up(eng, a), _up(eng, b), eng.DeviceBuffer(a.nbytes)
+        e.multiply(dR, dA, dB, batch)
+        assert hashlib.sha256(dR.download(a.shape).tobytes()).hexdigest() == c["polymul_sha256"]
+        e.forward(dA, batch)
+        fa = dA.download(a.shape)
+        assert hashlib.sha256(fa.tobytes()).hexdigest() == c["forward_sha256"]
+        assert [int(v) for v in fa[0, 0, :8, 0]] == c["forward_first8"]
