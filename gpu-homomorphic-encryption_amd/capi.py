@@ -153,6 +153,7 @@ class DeviceBuffer:
 
     def download(self, shape=None, dtype=np.uint64):
         out = np.empty(self.nbytes // np.dtype(dtype).itemsize, dtype=dtype)
+        _check(lib().fhe_hip_sync())      # engines enqueue asynchronously; callers synchronise (tests/test_fhe.cu:88)
         _check(lib().fhe_hip_memcpy_d2h(out.ctypes.data, self.ptr, self.nbytes))
         return out.reshape(shape) if shape is not None else out.reshape(-1, 4)
 

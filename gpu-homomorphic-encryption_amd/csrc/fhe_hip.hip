@@ -183,7 +183,7 @@ struct fhe_rns_ntt {
     uint32_t n = 0, log_n = 0, L = 0;
     int width = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
-    void *d_limbs = nullptr;
+    void *d_limbs = nullptr;            // owned by d_tables
     std::vector<void *> d_tables;
     void *d_ws = nullptr; size_t ws_bytes = 0;
     uint32_t *d_flag = nullptr;
@@ -194,7 +194,6 @@ struct fhe_ntt { fhe_rns_ntt *impl; };
 static void destroy_impl(fhe_rns_ntt *h) {
     if (!h) return;
     for (void *p : h->d_tables) (void)hipFree(p);
-    if (h->d_limbs) (void)hipFree(h->d_limbs);
     if (h->d_ws) (void)hipFree(h->d_ws);
     if (h->d_flag) (void)hipFree(h->d_flag);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -331,7 +330,8 @@ static int create_impl(fhe_rns_ntt **out, uint32_t n, const uint64_t (*moduli)[4
     else h->width = FHE_WIDTH_256;
 #define TRY_OR_DESTROY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { destroy_impl(h); return fail(FHE_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); } } while (0)
     TRY_OR_DESTROY(hipGetDevice(&h->device));
-    TRY_OR_DESTROY(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
+    TRY_OR_DESTROY(hipStreamCreate(&h->own_stream));   // blocking stream, like the reference's cudaStreamCreate (src/ntt.cu:18):
+                                                       // a later hipMemcpy on the null stream is ordered after our kernels
     h->stream = h->own_stream;
     TRY_OR_DESTROY(hipMalloc((void **)&h->d_flag, sizeof(uint32_t)));
     TRY_OR_DESTROY(hipMemset(h->d_flag, 0, sizeof(uint32_t)));
@@ -346,6 +346,7 @@ static int check_call(const fhe_rns_ntt *h, uint32_t batch, const char *what) {
     if (!h) return fail(FHE_ERR_INVALID_ARG, std::string(what) + ": null handle");
     if (!batch) return fail(FHE_ERR_INVALID_ARG, std::string(what) + ": batch must be >= 1");
     if ((uint64_t)batch * h->L > 0x7fffffffull) return fail(FHE_ERR_INVALID_ARG, std::string(what) + ": batch * num_primes too large");
+    (void)hipGetLastError();            // drop any stale sticky error so post_launch reports only this call's
     return FHE_OK;
 }
 
