@@ -61,7 +61,9 @@ def cpu_baseline(n, moduli, target_core_seconds=16.0):
     from oracle import pyoracle as orc
     from workload import rns_poly
     orc.build()
-    cores = min(orc.max_threads(), os.cpu_count() or 1)
+    # the GPU box gives one GPU a 16-core share of the host; never oversubscribe it
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = max(1, min(orc.max_threads(), avail, int(os.environ.get("FHE_BENCH_CPU_THREADS", "16"))))
     rp = orc.RnsPlan(n, moduli)
     a = rns_poly(7, moduli, n, 1); b = rns_poly(8, moduli, n, 1)
     t0 = time.perf_counter(); rp.polymul(a, b, threads=1); one = time.perf_counter() - t0
@@ -74,6 +76,26 @@ def cpu_baseline(n, moduli, target_core_seconds=16.0):
                       f"OpenMP over batch x limb; single-thread {one * 1e3:.1f} ms/polymul)"}
 
 
+def pmc_traffic(kernel_substr, n, limbs, bits, batch):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
+    (profiles/<tag>_summary.json, written by scripts/summarize_profile.py; FETCH_SIZE doubled as the
+    gfx950 guide prescribes).  None when no profile of this exact workload is committed."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_summary.json"))):
+        try:
+            d = json.load(open(f))
+            cfg = d.get("bench_line_under_profiler", {}).get("config", {})
+            if (cfg.get("n"), cfg.get("limbs"), cfg.get("prime_bits"), cfg.get("batch_per_gpu")) != (n, limbs, bits, batch):
+                continue
+            for name, k in d["kernels"].items():
+                if kernel_substr in name and "hbm_bytes_per_launch" in k:
+                    best = {"bytes": k["hbm_bytes_per_launch"], "source": os.path.basename(f)}
+        except Exception:
+            continue
+    return best
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -81,10 +103,10 @@ def main():
     dist = None
     if world > 1:
         import torch                       # first, so the process has ONE libamdhip64 (same SONAME as ours)
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     pkg = importlib.import_module("gpu-homomorphic-encryption_amd")
+    sharding = importlib.import_module("gpu-homomorphic-encryption_amd.sharding")
+    if world > 1:
+        dist = sharding.init_process_group("nccl")     # RCCL: barriers + max-over-ranks only, no payload collective
     if pkg.device_count() < 1:
         raise SystemExit("bench.py: no HIP device; the engine has no CPU fallback")
     if world > 1:
@@ -121,11 +143,7 @@ def main():
             dist.barrier()
         wall = time.perf_counter() - t0
         ev_ms = timer.elapsed_ms()
-        if dist is not None:
-            import torch
-            t = torch.tensor([wall, ev_ms], dtype=torch.float64, device="cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            wall, ev_ms = float(t[0]), float(t[1])
+        wall, ev_ms = sharding.max_over_ranks(dist, [wall, ev_ms], device="cuda" if dist is not None else "cpu")
         return wall, ev_ms
 
     wall, ev_ms = timed(lambda: eng.multiply(dR, dA, dB, B), args.steps, args.warmup)
@@ -144,9 +162,13 @@ def main():
                                f"({args.bits}-bit primes), batch {B} polynomial pairs per GPU, 32-byte containers",
                    "n": n, "limbs": L, "prime_bits": args.bits, "batch_per_gpu": B, "parallelism": f"batch-shard x{world}"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "traffic_source": None,
                      "kernel": "ntt_multiply_kernel", "launch_ms": launch_ms, "algorithmic_bytes_per_launch": algo_bytes},
     }
+    tr = pmc_traffic("ntt_multiply_kernel", n, L, args.bits, B)
+    if tr:
+        out["roofline"]["traffic"] = tr["bytes"]
+        out["roofline"]["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes, profiles/" + tr["source"]
     if args.extras:
         w2, e2 = timed(lambda: (eng.forward(dA, B), eng.inverse(dA, B)), args.steps, args.warmup)
         pair_ms = e2 / args.steps

@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Turns gpurun_out/<tag>/ (written by scripts/profile_bench.sh on the GPU box) into the committed
+profiles/<tag>_kernel_stats.csv + profiles/<tag>_summary.json.
+
+HBM traffic follows /opt/skills/guides/MI355X_MICROARCH.md "HBM": FETCH_SIZE / WRITE_SIZE are in KiB and
+come from separate --pmc passes; on gfx950 FETCH_SIZE reports half of the bytes a streaming read
+fetches, so it is doubled; WRITE_SIZE is exact for 16-byte-per-lane streaming stores."""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+src = os.path.join("gpurun_out", tag)
+os.makedirs("profiles", exist_ok=True)
+
+
+def one(pattern):
+    fs = sorted(glob.glob(os.path.join(src, pattern)))
+    return fs[0] if fs else None
+
+
+summary = {"tag": tag, "kernels": {}}
+stats = one("trace/*/*_kernel_stats.csv")
+if stats:
+    shutil.copy(stats, f"profiles/{tag}_kernel_stats.csv")
+    for r in csv.DictReader(open(stats)):
+        summary["kernels"][r["Name"]] = {"calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]), "min_ns": float(r["MinNs"]),
+                                         "max_ns": float(r["MaxNs"]), "pct": float(r["Percentage"])}
+trace = one("trace/*/*_kernel_trace.csv")
+if trace:
+    rows = list(csv.DictReader(open(trace)))
+    res = {}
+    for r in rows:
+        res.setdefault(r["Kernel_Name"], {"vgpr": r.get("VGPR_Count"), "sgpr": r.get("SGPR_Count"), "lds": r.get("LDS_Block_Size"),
+                                          "scratch": r.get("Scratch_Size"), "wg": r.get("Workgroup_Size"), "grid": r.get("Grid_Size")})
+    for k, v in res.items():
+        summary["kernels"].setdefault(k, {}).update(v)
+for kind, key in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+    f = one(f"pmc_{kind}/*/*_counter_collection.csv")
+    if not f:
+        continue
+    shutil.copy(f, f"profiles/{tag}_pmc_{kind}.csv")
+    acc = {}
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] == key:
+            acc.setdefault(r["Kernel_Name"], []).append(float(r["Counter_Value"]))
+    for k, vals in acc.items():
+        kib = sum(vals) / len(vals)
+        d = summary["kernels"].setdefault(k, {})
+        d[key + "_KiB_per_launch_raw"] = kib
+        if key == "FETCH_SIZE":
+            d["hbm_read_bytes_per_launch"] = kib * 1024 * 2      # gfx950: counter reports 1/2 of streamed bytes
+        else:
+            d["hbm_write_bytes_per_launch"] = kib * 1024
+for k, d in summary["kernels"].items():
+    if "hbm_read_bytes_per_launch" in d and "hbm_write_bytes_per_launch" in d:
+        d["hbm_bytes_per_launch"] = d["hbm_read_bytes_per_launch"] + d["hbm_write_bytes_per_launch"]
+for log in ("bench_trace.log",):
+    p = os.path.join(src, log)
+    if os.path.exists(p):
+        for line in open(p):
+            if line.startswith("{") and '"metric"' in line:
+                summary["bench_line_under_profiler"] = json.loads(line)
+json.dump(summary, open(f"profiles/{tag}_summary.json", "w"), indent=1)
+print(json.dumps({k[:60]: {kk: vv for kk, vv in v.items() if kk in ("avg_ns", "hbm_bytes_per_launch", "vgpr", "calls")}
+                  for k, v in summary["kernels"].items()}, indent=1))

@@ -1,0 +1,201 @@
+// test_fhe_mirror.cpp -- the reference's test scenarios (tests/test_fhe.cu:24-318) on the hot path, run
+// through the C++ mirror classes (include/fhe/*.hpp) and ASSERTED (the reference only prints).
+// Expected values are computed here on the host with plain 64/128-bit arithmetic (schoolbook).
+//   ./test_fhe_mirror             full run (needs the MI355X)
+//   ./test_fhe_mirror --host-only parameter maths only (no device)
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+#include <vector>
+
+#include "fhe/fhe.hpp"
+
+using namespace fhe;
+typedef unsigned __int128 u128;
+
+#define REQUIRE(cond)                                                                       \
+    do {                                                                                    \
+        if (!(cond)) { std::fprintf(stderr, "FAILED %s:%d: %s\n", __FILE__, __LINE__, #cond); std::exit(1); } \
+    } while (0)
+
+static std::vector<uint64_t> schoolbook_negacyclic(const std::vector<uint64_t> &a, const std::vector<uint64_t> &b, uint64_t q) {
+    size_t n = a.size();
+    std::vector<uint64_t> r(n, 0);
+    for (size_t i = 0; i < n; i++) {
+        if (!a[i]) continue;
+        for (size_t j = 0; j < n; j++) {
+            uint64_t p = (uint64_t)((u128)a[i] * b[j] % q);
+            size_t k = i + j;
+            if (k < n) r[k] = (r[k] + p) % q;
+            else r[k - n] = (r[k - n] + q - p) % q;
+        }
+    }
+    return r;
+}
+static std::vector<uint256_t> widen(const std::vector<uint64_t> &v) { return std::vector<uint256_t>(v.begin(), v.end()); }
+
+static void test_host_parameters() {
+    std::cout << "Testing host parameter maths..." << std::endl;
+    MontgomeryParams p = compute_montgomery_params(uint256_t(12289));
+    REQUIRE(p.inv.limbs[0] == 0x2faf01aff7002fffull && p.inv.limbs[1] == 0);
+    REQUIRE(p.r_squared.limbs[0] == 10889);                                          // R^2 mod 12289
+    REQUIRE(compute_montgomery_inverse(uint256_t(1ull << 60)).limbs[0] == 0xffffffffffffffc0ull);   // even-modulus garbage, literal
+    uint256_t psi = find_primitive_root(1024, uint256_t(12289));
+    uint64_t x = 1; for (int i = 0; i < 1024; i++) x = x * psi.limbs[0] % 12289;
+    REQUIRE(x == 12288);                                                             // psi^n = -1
+    bool threw = false;
+    try { find_primitive_root(1024, uint256_t(12291)); } catch (const std::runtime_error &) { threw = true; }
+    REQUIRE(threw);
+    std::cout << "  ok" << std::endl;
+}
+
+// tests/test_fhe.cu:24-63
+static void test_bigint_arithmetic() {
+    std::cout << "Testing BigInt Arithmetic..." << std::endl;
+    uint256_t *d_a = device_alloc(1), *d_b = device_alloc(1), *d_r = device_alloc(1);
+    uint256_t h_a(12345, 0, 0, 0), h_b(67890, 0, 0, 0), h_mod(100000, 0, 0, 0), h_r;
+    copy_to_device(d_a, &h_a, 1); copy_to_device(d_b, &h_b, 1);
+    batch_mod_add(d_r, d_a, d_b, h_mod, 1); device_synchronize(); copy_to_host(&h_r, d_r, 1);
+    std::cout << "  Addition: 12345 + 67890 = " << h_r.limbs[0] << " (mod 100000)" << std::endl;
+    REQUIRE(h_r == uint256_t(80235));
+    batch_mod_sub(d_r, d_a, d_b, h_mod, 1); device_synchronize(); copy_to_host(&h_r, d_r, 1);
+    std::cout << "  Subtraction: 12345 - 67890 = " << h_r.limbs[0] << " (mod 100000)" << std::endl;
+    REQUIRE(h_r == uint256_t(44455));
+    device_free(d_a); device_free(d_b); device_free(d_r);
+}
+
+// tests/test_fhe.cu:65-124
+static void test_ntt_transform() {
+    std::cout << "Testing NTT Transform..." << std::endl;
+    const uint32_t N = 1024;
+    uint256_t modulus(12289, 0, 0, 0);
+    NTTEngine ntt(N, modulus);
+    std::vector<uint256_t> h_data(N), h_fwd(N), h_back(N);
+    for (uint32_t i = 0; i < N; i++) h_data[i] = uint256_t(i + 1);
+    uint256_t *d = device_alloc(N);
+    copy_to_device(d, h_data.data(), N);
+    ntt.forward(d); device_synchronize(); copy_to_host(h_fwd.data(), d, N);
+    ntt.inverse(d); device_synchronize(); copy_to_host(h_back.data(), d, N);
+    bool changed = false;
+    for (uint32_t i = 0; i < N; i++) { REQUIRE(h_back[i] == h_data[i]); REQUIRE(h_fwd[i].limbs[0] < 12289); changed |= h_fwd[i] != h_data[i]; }
+    REQUIRE(changed);
+    // X[0] = sum_j x[j] psi^j  (bitrev(0) = 0)
+    uint64_t psi = find_primitive_root(N, modulus).limbs[0], acc = 0, pw = 1;
+    for (uint32_t j = 0; j < N; j++) { acc = (acc + (j + 1) * pw) % 12289; pw = pw * psi % 12289; }
+    REQUIRE(h_fwd[0].limbs[0] == acc);
+    device_free(d);
+    std::cout << "  round trip ok, X[0] matches the definition" << std::endl;
+}
+
+// tests/test_fhe.cu:126-167 (the reference never reads the product back)
+static void test_polynomial_multiplication() {
+    std::cout << "Testing Polynomial Multiplication..." << std::endl;
+    const uint32_t N = 2048;
+    uint256_t modulus(40961, 0, 0, 0);
+    NTTEngine ntt(N, modulus);
+    PolynomialOps ops(N, modulus, &ntt);
+    std::vector<uint64_t> a(N), b(N);
+    srand(1);
+    for (uint32_t i = 0; i < N; i++) { a[i] = rand() % 100; b[i] = rand() % 100; }
+    Polynomial pa(N, modulus), pb(N, modulus), pr(N, modulus), ps(N, modulus);
+    auto wa = widen(a), wb = widen(b);
+    copy_to_device(pa.coeffs, wa.data(), N); copy_to_device(pb.coeffs, wb.data(), N);
+    ops.mul_ntt(pr, pa, pb);
+    ops.add(ps, pa, pb);
+    device_synchronize();
+    std::vector<uint256_t> got(N), sum(N), a_after(N);
+    copy_to_host(got.data(), pr.coeffs, N); copy_to_host(sum.data(), ps.coeffs, N); copy_to_host(a_after.data(), pa.coeffs, N);
+    auto want = schoolbook_negacyclic(a, b, 40961);
+    for (uint32_t i = 0; i < N; i++) {
+        REQUIRE(got[i] == uint256_t(want[i]));
+        REQUIRE(sum[i] == uint256_t((a[i] + b[i]) % 40961));
+        REQUIRE(a_after[i] == uint256_t(a[i]));                                    // operands preserved (src/ntt.cu:50-58)
+    }
+    std::cout << "  product matches schoolbook, operands preserved" << std::endl;
+}
+
+// tests/test_fhe.cu:169-273, multiply path only: the tensor product of two 2-component ciphertexts
+static void test_fhe_multiply() {
+    std::cout << "Testing FHEContext::multiply (tensor product)..." << std::endl;
+    SecurityParams sp{128, 4096, 120, 3.2f, 64};
+    FHEContext ctx(sp);
+    const SchemeParams &P = ctx.params();
+    const uint32_t N = P.n, L = (uint32_t)P.rns_moduli.size();
+    REQUIRE(L == 4);
+    for (auto &q : P.rns_moduli) REQUIRE(q.limbs[0] >> 29 == 1 && q.limbs[0] % (2 * N) == 1);
+    Ciphertext A, B, C, S;
+    std::vector<std::vector<uint64_t>> host[4];     // a0, a1, b0, b1 : [L][N]
+    srand(7);
+    for (int c = 0; c < 4; c++) {
+        Polynomial *p = ctx.new_polynomial();
+        host[c].assign(L, std::vector<uint64_t>(N));
+        std::vector<uint256_t> flat((size_t)L * N);
+        for (uint32_t l = 0; l < L; l++)
+            for (uint32_t i = 0; i < N; i++) {
+                uint64_t v = (((uint64_t)rand() << 20) ^ (uint64_t)rand()) % P.rns_moduli[l].limbs[0];
+                host[c][l][i] = v; flat[(size_t)l * N + i] = uint256_t(v);
+            }
+        copy_to_device(p->coeffs, flat.data(), flat.size());
+        (c < 2 ? A : B).components.push_back(p);
+    }
+    RelinKeys rlk;
+    ctx.multiply(C, A, B, rlk);
+    ctx.add(S, A, B);
+    device_synchronize();
+    REQUIRE(C.components.size() == 3 && S.components.size() == 2);
+    std::vector<uint256_t> c[3];
+    for (int k = 0; k < 3; k++) { c[k].resize((size_t)L * N); copy_to_host(c[k].data(), C.components[k]->coeffs, c[k].size()); }
+    for (uint32_t l : {0u, L - 1}) {
+        uint64_t q = P.rns_moduli[l].limbs[0];
+        auto c0 = schoolbook_negacyclic(host[0][l], host[2][l], q);
+        auto t1 = schoolbook_negacyclic(host[0][l], host[3][l], q);
+        auto t2 = schoolbook_negacyclic(host[1][l], host[2][l], q);
+        auto c2 = schoolbook_negacyclic(host[1][l], host[3][l], q);
+        for (uint32_t i = 0; i < N; i++) {
+            REQUIRE(c[0][(size_t)l * N + i] == uint256_t(c0[i]));
+            REQUIRE(c[1][(size_t)l * N + i] == uint256_t((t1[i] + t2[i]) % q));
+            REQUIRE(c[2][(size_t)l * N + i] == uint256_t(c2[i]));
+        }
+    }
+    std::vector<uint256_t> s0((size_t)L * N);
+    copy_to_host(s0.data(), S.components[0]->coeffs, s0.size());
+    for (uint32_t l = 0; l < L; l++)
+        for (uint32_t i = 0; i < N; i += 97) REQUIRE(s0[(size_t)l * N + i] == uint256_t((host[0][l][i] + host[2][l][i]) % P.rns_moduli[l].limbs[0]));
+    std::cout << "  c0, c1, c2 match schoolbook on limbs 0 and " << L - 1 << std::endl;
+}
+
+// tests/test_fhe.cu:275-318 shape (N = 8192), timing the multiply path instead of encrypt
+static void benchmark_multiply() {
+    std::cout << "Benchmark: ciphertext tensor product, N = 8192, log_q = 120" << std::endl;
+    SecurityParams sp{128, 8192, 120, 3.2f, 64};
+    FHEContext ctx(sp);
+    Ciphertext A, B, C;
+    for (int c = 0; c < 4; c++) (c < 2 ? A : B).components.push_back(ctx.new_polynomial());
+    RelinKeys rlk;
+    ctx.multiply(C, A, B, rlk); device_synchronize();
+    auto t0 = std::chrono::high_resolution_clock::now();
+    const int iters = 100;
+    for (int i = 0; i < iters; i++) ctx.multiply(C, A, B, rlk);
+    device_synchronize();
+    double ms = std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t0).count();
+    std::cout << "  " << ms / iters << " ms per multiply (batch 1, launch-bound), " << iters * 1000.0 / ms << " ops/s" << std::endl;
+}
+
+int main(int argc, char **argv) {
+    test_host_parameters();
+    if (argc > 1 && !std::strcmp(argv[1], "--host-only")) { std::cout << "host-only: PASSED" << std::endl; return 0; }
+    int count = 0;
+    check(fhe_hip_device_count(&count), "device count");
+    REQUIRE(count > 0);
+    char name[256]; check(fhe_hip_device_name(name, sizeof name), "device name");
+    std::cout << "Device: " << name << std::endl;
+    test_bigint_arithmetic();
+    test_ntt_transform();
+    test_polynomial_multiplication();
+    test_fhe_multiply();
+    benchmark_multiply();
+    std::cout << "ALL PASSED" << std::endl;
+    return 0;
+}

@@ -1,0 +1,43 @@
+"""Builds tests/cpp/test_fhe_mirror.cpp against include/fhe/*.hpp + libfhe_hip.so with g++ (the host
+side of the reference is compiled C++, so its mirror is too) and runs it: host-only on CPU, the full
+reference scenarios on the GPU box."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "tests", "cpp", "test_fhe_mirror.cpp")
+OUT_DIR = os.path.join(ROOT, "tests", "cpp", "_build")
+EXE = os.path.join(OUT_DIR, "test_fhe_mirror")
+
+
+def _build(pkg):
+    pkg.build_library()
+    lib_dir = os.path.dirname(pkg.library_path())
+    os.makedirs(OUT_DIR, exist_ok=True)
+    deps = [SRC] + [os.path.join(ROOT, "include", "fhe", f) for f in os.listdir(os.path.join(ROOT, "include", "fhe"))]
+    deps.append(os.path.join(ROOT, "include", "fhe_hip.h"))
+    if os.path.exists(EXE) and all(os.path.getmtime(EXE) >= os.path.getmtime(d) for d in deps):
+        return EXE
+    cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-Wextra", "-I", os.path.join(ROOT, "include"), SRC, "-L", lib_dir, "-lfhe_hip",
+           f"-Wl,-rpath,{lib_dir}", "-Wl,-rpath,/opt/rocm/lib", "-o", EXE]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+    return EXE
+
+
+def test_cpp_mirror_compiles_and_host_maths_pass(pkg):
+    exe = _build(pkg)
+    res = subprocess.run([exe, "--host-only"], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert "host-only: PASSED" in res.stdout
+
+
+@pytest.mark.gpu
+def test_cpp_mirror_reference_scenarios_on_gpu(pkg):
+    exe = _build(pkg)
+    res = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    print(res.stdout)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert "ALL PASSED" in res.stdout
