@@ -34,12 +34,16 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=1024, help="polynomial pairs per GPU per step")
+    ap.add_argument("--batch", type=int, default=4096,
+                    help="polynomial pairs per GPU per step (4096 = the plateau of the batch sweep 1/64/1024/4096; 12 GiB of a, b, r)")
     ap.add_argument("--n", type=int, default=8192)
     ap.add_argument("--limbs", type=int, default=4)
     ap.add_argument("--bits", type=int, default=30, help="bit length of each RNS prime (30 = log_q 120 / 4 limbs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--extras", action="store_true", help="also time forward+inverse pairs and the ciphertext tensor product")
+    ap.add_argument("--op", choices=["multiply", "fwdinv", "ct"], default="multiply",
+                    help="multiply = fused polymul (the headline, configs[1]); fwdinv = forward+inverse NTT pair; "
+                         "ct = ciphertext tensor product (configs[2]/[3] without relinearisation)")
+    ap.add_argument("--extras", action="store_true", help="also time forward+inverse pairs")
     return ap.parse_args()
 
 
@@ -76,7 +80,7 @@ def cpu_baseline(n, moduli, target_core_seconds=16.0):
                       f"OpenMP over batch x limb; single-thread {one * 1e3:.1f} ms/polymul)"}
 
 
-def pmc_traffic(kernel_substr, n, limbs, bits, batch):
+def pmc_traffic(kernel_substr, op, n, limbs, bits, batch):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
     (profiles/<tag>_summary.json, written by scripts/summarize_profile.py; FETCH_SIZE doubled as the
     gfx950 guide prescribes).  None when no profile of this exact workload is committed."""
@@ -86,7 +90,7 @@ def pmc_traffic(kernel_substr, n, limbs, bits, batch):
         try:
             d = json.load(open(f))
             cfg = d.get("bench_line_under_profiler", {}).get("config", {})
-            if (cfg.get("n"), cfg.get("limbs"), cfg.get("prime_bits"), cfg.get("batch_per_gpu")) != (n, limbs, bits, batch):
+            if (cfg.get("op", "multiply"), cfg.get("n"), cfg.get("limbs"), cfg.get("prime_bits"), cfg.get("batch_per_gpu")) != (op, n, limbs, bits, batch):
                 continue
             for name, k in d["kernels"].items():
                 if kernel_substr in name and "hbm_bytes_per_launch" in k:
@@ -117,10 +121,27 @@ def main():
     moduli = pkg.find_ntt_primes(args.bits, n, L)
     eng = pkg.RnsNttEngine(n, moduli)
     S = 32 * n * L                                   # bytes of one RNS polynomial
-    dA, dB, dR = pkg.DeviceBuffer(B * S), pkg.DeviceBuffer(B * S), pkg.DeviceBuffer(B * S)
-    fill_device(pkg, dA, 1000 + rank * 100000, moduli, n, B)
-    fill_device(pkg, dB, 5000 + rank * 100000, moduli, n, B)
-    dR.zero()
+    n_in, n_out = {"multiply": (2, 1), "fwdinv": (1, 0), "ct": (4, 3)}[args.op]
+    ins = [pkg.DeviceBuffer(B * S) for _ in range(n_in)]
+    outs = [pkg.DeviceBuffer(B * S) for _ in range(n_out)]
+    for i, buf in enumerate(ins):
+        fill_device(pkg, buf, 1000 + 4000 * i + rank * 100000, moduli, n, B)
+    for buf in outs:
+        buf.zero()
+    if args.op == "multiply":
+        dA, dB = ins; dR = outs[0]
+        step = lambda: eng.multiply(dR, dA, dB, B)
+        unit, units_per_poly_bytes, kernel = "polymul/s", 3, "ntt_multiply_kernel"
+        what = "forward+inverse NTT + pointwise mul (fused polymul)"
+    elif args.op == "fwdinv":
+        dA = ins[0]
+        step = lambda: (eng.forward(dA, B), eng.inverse(dA, B))
+        unit, units_per_poly_bytes, kernel = "ntt-pair/s", 4, "ntt_forward_kernel+ntt_inverse_kernel"
+        what = "batched forward + inverse NTT pair (in place)"
+    else:
+        step = lambda: eng.ct_multiply(outs[0], outs[1], outs[2], ins[0], ins[1], ins[2], ins[3], B)
+        unit, units_per_poly_bytes, kernel = "ct-mul/s", 7, "ntt_ct_multiply_kernel"
+        what = "ciphertext tensor product c0=a0b0, c1=a0b1+a1b0, c2=a1b1 (no relinearisation)"
 
     def barrier():
         pkg.capi.sync()
@@ -146,35 +167,38 @@ def main():
         wall, ev_ms = sharding.max_over_ranks(dist, [wall, ev_ms], device="cuda" if dist is not None else "cpu")
         return wall, ev_ms
 
-    wall, ev_ms = timed(lambda: eng.multiply(dR, dA, dB, B), args.steps, args.warmup)
+    wall, ev_ms = timed(step, args.steps, args.warmup)
     ms_per_step = wall * 1e3 / args.steps
     value = B * world / (wall / args.steps)
-    launch_ms = ev_ms / args.steps                   # one kernel launch per step on the 32/64-bit paths
-    algo_bytes = 3 * S * B                           # read a, read b, write r  (3*S per polymul)
+    launch_ms = ev_ms / args.steps                   # HIP-event time of one step's launches on the engine stream
+    algo_bytes = units_per_poly_bytes * S * B        # 3*S per polymul, 4*S per fwd+inv pair, 7*S per ct-mul
     achieved = algo_bytes / (launch_ms * 1e-3) / 1e9
     width = {1: "u32", 2: "u64", 4: "u256"}[eng.width_class]
+    metric = "NTT-polymul/sec (N=8192, 4 RNS limbs) + achieved HBM GB/s vs peak"
+    if (args.op, n, L) != ("multiply", 8192, 4):
+        metric = f"{unit[:-2]}/sec (N={n}, {L} RNS limbs) + achieved HBM GB/s vs peak"
     out = {
-        "metric": "NTT-polymul/sec (N=8192, 4 RNS limbs) + achieved HBM GB/s vs peak",
-        "value": value, "unit": "polymul/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "metric": metric,
+        "value": value, "unit": unit, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": width, "data": "synthetic",
-        "config": {"workload": f"configs[1]: forward+inverse NTT + pointwise mul (fused polymul), N={n}, {L} RNS limbs "
-                               f"({args.bits}-bit primes), batch {B} polynomial pairs per GPU, 32-byte containers",
-                   "n": n, "limbs": L, "prime_bits": args.bits, "batch_per_gpu": B, "parallelism": f"batch-shard x{world}"},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "config": {"workload": f"{'configs[1]: ' if args.op == 'multiply' else ''}{what}, N={n}, {L} RNS limbs "
+                               f"({args.bits}-bit primes), batch {B} per GPU, 32-byte containers",
+                   "op": args.op, "n": n, "limbs": L, "prime_bits": args.bits, "batch_per_gpu": B, "parallelism": f"batch-shard x{world}"},
+        "roofline": {"bound": "hbm" if eng.width_class != 4 else "valu-int", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None, "traffic_source": None,
-                     "kernel": "ntt_multiply_kernel", "launch_ms": launch_ms, "algorithmic_bytes_per_launch": algo_bytes},
+                     "kernel": kernel, "launch_ms": launch_ms, "algorithmic_bytes_per_launch": algo_bytes},
     }
-    tr = pmc_traffic("ntt_multiply_kernel", n, L, args.bits, B)
+    tr = pmc_traffic(kernel.split("+")[0], args.op, n, L, args.bits, B)
     if tr:
         out["roofline"]["traffic"] = tr["bytes"]
         out["roofline"]["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes, profiles/" + tr["source"]
-    if args.extras:
+    if args.extras and args.op == "multiply":
         w2, e2 = timed(lambda: (eng.forward(dA, B), eng.inverse(dA, B)), args.steps, args.warmup)
         pair_ms = e2 / args.steps
         out["extra_fwd_inv_pairs"] = {"pairs_per_s": B * world / (w2 / args.steps), "achieved_GBps": 4 * S * B / (pair_ms * 1e-3) / 1e9,
                                       "frac": 4 * S * B / (pair_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.op == "multiply":
         out["cpu_baseline"] = cpu_baseline(n, moduli)
     if rank == 0:
         print(json.dumps(out), flush=True)

@@ -18,7 +18,7 @@ def splitmix64_block(seed, count):
 
 def rns_poly(seed, moduli, n, batch):
     """[batch][L][n][4] uint64, residues < q_l.  Word-sized moduli: one stream word per coefficient;
-    wider moduli: four words reduced with Python ints (small sizes only)."""
+    wider moduli: four words truncated below q."""
     L = len(moduli)
     out = np.zeros((batch, L, n, 4), dtype=np.uint64)
     for b in range(batch):
@@ -27,9 +27,15 @@ def rns_poly(seed, moduli, n, batch):
             if q < (1 << 64):
                 out[b, l, :, 0] = splitmix64_block(sd, n) % np.uint64(q)
             else:
+                # wider moduli: four stream words per coefficient, truncated to bit_length(q) - 1 bits
+                # (< 2^(bits-1) <= q, so no reduction is needed and the fill stays vectorised)
                 w = splitmix64_block(sd, 4 * n).reshape(n, 4)
-                for i in range(n):
-                    v = (int(w[i, 0]) | (int(w[i, 1]) << 64) | (int(w[i, 2]) << 128) | (int(w[i, 3]) << 192)) % q
-                    for k in range(4):
-                        out[b, l, i, k] = (v >> (64 * k)) & 0xFFFFFFFFFFFFFFFF
+                keep = q.bit_length() - 1
+                for k in range(4):
+                    lo = 64 * k
+                    if keep <= lo:
+                        w[:, k] = 0
+                    elif keep < lo + 64:
+                        w[:, k] &= np.uint64((1 << (keep - lo)) - 1)
+                out[b, l] = w
     return out
