@@ -173,7 +173,7 @@ def main():
     launch_ms = ev_ms / args.steps                   # HIP-event time of one step's launches on the engine stream
     algo_bytes = units_per_poly_bytes * S * B        # 3*S per polymul, 4*S per fwd+inv pair, 7*S per ct-mul
     achieved = algo_bytes / (launch_ms * 1e-3) / 1e9
-    width = {1: "u32", 2: "u64", 4: "u256"}[eng.width_class]
+    width = {1: "u32", 2: "u64", 3: "f64 (exact integers < 2^53)", 4: "u256"}[eng.width_class]
     metric = "NTT-polymul/sec (N=8192, 4 RNS limbs) + achieved HBM GB/s vs peak"
     if (args.op, n, L) != ("multiply", 8192, 4):
         metric = f"{unit[:-2]}/sec (N={n}, {L} RNS limbs) + achieved HBM GB/s vs peak"

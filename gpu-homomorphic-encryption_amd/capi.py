@@ -7,7 +7,7 @@ import numpy as np
 
 from .build import library_path
 
-WIDTH_32, WIDTH_64, WIDTH_256 = 1, 2, 4
+WIDTH_32, WIDTH_64, WIDTH_52, WIDTH_256 = 1, 2, 3, 4
 _lib = None
 
 U64x4 = ctypes.c_uint64 * 4

@@ -275,6 +275,33 @@ static int build_limbs64(fhe_rns_ntt *h, const std::vector<fhe_host::NttConstant
     return upload(h, limbs, &h->d_limbs);
 }
 
+static int build_limbs52(fhe_rns_ntt *h, const std::vector<fhe_host::NttConstants> &cs) {
+    std::vector<fhe_dev::Limb52> limbs(h->L);
+    for (uint32_t l = 0; l < h->L; l++) {
+        const fhe_host::NttConstants &c = cs[l];
+        const double q = (double)c.q.w[0];                 // q < 2^43: exact
+        const uint64_t qi = c.q.w[0], n = h->n;
+        std::vector<double2> tw(n), itw(n);
+        for (uint32_t k = 0; k < n; k++) {
+            tw[k] = make_double2((double)c.tw[k].w[0], (double)c.tw[k].w[0] / q);      // companion = fl(w / q)
+            itw[k] = make_double2((double)c.itw[k].w[0], (double)c.itw[k].w[0] / q);
+        }
+        fhe_dev::Limb52 &P = limbs[l];
+        std::memset(&P, 0, sizeof(P));
+        auto mulq = [qi](uint64_t a, uint64_t b) { return (uint64_t)(((fhe_host::u128)a * b) % qi); };
+        const uint64_t ninv = c.n_inv.w[0], nw = mulq(ninv, c.itw[1].w[0]);
+        P.q = q; P.q2 = 2 * q; P.qinv = 1.0 / q;
+        P.r1 = 1.0; P.r1_s = 1.0 / q;                       // no Montgomery factor on this path
+        P.ninv = (double)ninv; P.ninv_s = (double)ninv / q;
+        P.ninvw = (double)nw; P.ninvw_s = (double)nw / q;
+        P.ninv_r = P.ninv; P.ninv_r_s = P.ninv_s; P.ninvw_r = P.ninvw; P.ninvw_r_s = P.ninvw_s;
+        void *d = nullptr; int rc;
+        if ((rc = upload(h, tw, &d))) return rc; P.tw = (const double2 *)d;
+        if ((rc = upload(h, itw, &d))) return rc; P.itw = (const double2 *)d;
+    }
+    return upload(h, limbs, &h->d_limbs);
+}
+
 static int build_limbs256(fhe_rns_ntt *h, const std::vector<fhe_host::NttConstants> &cs) {
     std::vector<fhe_dev::Limb256> limbs(h->L);
     for (uint32_t l = 0; l < h->L; l++) {
@@ -323,9 +350,11 @@ static int create_impl(fhe_rns_ntt **out, uint32_t n, const uint64_t (*moduli)[4
     h->n = n; h->L = L; while ((1u << h->log_n) < n) h->log_n++;
     for (uint32_t l = 0; l < L; l++) h->moduli.push_back(cs[l].q);
     const bool lds_size = h->log_n >= 11 && h->log_n <= 15;
-    const char *force = getenv("FHE_HIP_FORCE_WIDTH");       // testing aid: "256" forces the general path
-    if (force && !strcmp(force, "256")) h->width = FHE_WIDTH_256;
-    else if (lds_size && max_bits <= 30 && !(force && !strcmp(force, "64"))) h->width = FHE_WIDTH_32;
+    const char *force = getenv("FHE_HIP_FORCE_WIDTH");       // testing aid: "52" / "64" / "256" force a wider path than needed
+    const int floor_w = force ? atoi(force) : 0;
+    if (floor_w >= 256) h->width = FHE_WIDTH_256;
+    else if (lds_size && max_bits <= 30 && floor_w < 52) h->width = FHE_WIDTH_32;
+    else if (lds_size && h->log_n <= 14 && max_bits <= 43 && floor_w < 64) h->width = FHE_WIDTH_52;
     else if (lds_size && h->log_n <= 14 && max_bits <= 62) h->width = FHE_WIDTH_64;
     else h->width = FHE_WIDTH_256;
 #define TRY_OR_DESTROY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { destroy_impl(h); return fail(FHE_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); } } while (0)
@@ -336,7 +365,8 @@ static int create_impl(fhe_rns_ntt **out, uint32_t n, const uint64_t (*moduli)[4
     TRY_OR_DESTROY(hipMalloc((void **)&h->d_flag, sizeof(uint32_t)));
     TRY_OR_DESTROY(hipMemset(h->d_flag, 0, sizeof(uint32_t)));
 #undef TRY_OR_DESTROY
-    rc = h->width == FHE_WIDTH_32 ? build_limbs32(h, cs) : h->width == FHE_WIDTH_64 ? build_limbs64(h, cs) : build_limbs256(h, cs);
+    rc = h->width == FHE_WIDTH_32 ? build_limbs32(h, cs) : h->width == FHE_WIDTH_52 ? build_limbs52(h, cs)
+         : h->width == FHE_WIDTH_64 ? build_limbs64(h, cs) : build_limbs256(h, cs);
     if (rc) { destroy_impl(h); return rc; }
     *out = h;
     return FHE_OK;
@@ -395,7 +425,7 @@ static int run256_ew(fhe_rns_ntt *h, void *r, const void *a, const void *b, uint
 // ---- LDS-resident path launchers (kernels live in lds_inst.hip, one object per (field, log2 n)) ---------
 static int lds_run(fhe_rns_ntt *h, int op, void *r0, void *r1, void *r2, const void *a0, const void *a1, const void *b0,
                    const void *b1, uint32_t polys, const char *what) {
-    fhe_dev::lds_launch_fn fn = fhe_dev::lds_lookup(h->width == FHE_WIDTH_32 ? 32 : 64, (int)h->log_n);
+    fhe_dev::lds_launch_fn fn = fhe_dev::lds_lookup(h->width == FHE_WIDTH_32 ? 32 : h->width == FHE_WIDTH_52 ? 52 : 64, (int)h->log_n);
     if (!fn) return fail(FHE_ERR_UNSUPPORTED, "transform size outside the LDS-resident range");
     fhe_dev::LdsArgs A{op, r0, r1, r2, a0, a1, b0, b1, h->d_limbs, h->L, polys, h->stream};
     fn(A);
@@ -434,6 +464,7 @@ template <int OP>
 static int do_ew(fhe_rns_ntt *h, void *r, const void *a, const void *b, uint32_t batch, const char *what) {
     const uint32_t polys = batch * h->L;
     if (h->width == FHE_WIDTH_32) return lds_ew<fhe_dev::F32, OP>(h, r, a, b, polys, what);
+    if (h->width == FHE_WIDTH_52) return lds_ew<fhe_dev::F52, OP>(h, r, a, b, polys, what);
     if (h->width == FHE_WIDTH_64) return lds_ew<fhe_dev::F64, OP>(h, r, a, b, polys, what);
     return run256_ew<OP>(h, r, a, b, polys, what);
 }
@@ -533,6 +564,7 @@ extern "C" int fhe_rns_check_canonical(fhe_rns_ntt_t *h, const void *d_data, uin
     const uint32_t polys = batch * h->L;
     HIP_TRY(hipMemsetAsync(h->d_flag, 0, sizeof(uint32_t), h->stream));
     if (h->width == FHE_WIDTH_32) rc = lds_check<fhe_dev::F32>(h, d_data, polys);
+    else if (h->width == FHE_WIDTH_52) rc = lds_check<fhe_dev::F52>(h, d_data, polys);
     else if (h->width == FHE_WIDTH_64) rc = lds_check<fhe_dev::F64>(h, d_data, polys);
     else {
         size_t count = (size_t)polys * h->n;

@@ -11,9 +11,7 @@ namespace fhe_dev {
 void CAT(lds_launch_, FHE_FIELD, FHE_LOGN)(const LdsArgs &A) {
     using F = FHE_FIELD;
     constexpr int LOGN = FHE_LOGN;
-    // waves per SIMD the fused multiply is compiled for: 4 workgroups of a 33 KiB-LDS F32 transform fit a CU (128-VGPR
-    // budget, measured +1..12 % over 3); the 64-bit residues need twice the registers and LDS
-    constexpr int MULT_MINW = sizeof(typename F::E) == 4 ? 4 : 2;
+    constexpr int MULT_MINW = F::MULT_MINW;
     const dim3 grid(A.polys), block(NttCfg<LOGN>::T);
     const Limb<F> *limbs = (const Limb<F> *)A.limbs;
     switch (A.op) {

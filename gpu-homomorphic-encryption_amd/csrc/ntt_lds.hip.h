@@ -1,6 +1,7 @@
 // ntt_lds.hip.h -- LDS-resident negacyclic NTT / polymul kernels for word-sized RNS primes on gfx950.
-//   F32 : q < 2^30, 32-bit residues  (FHE_WIDTH_32, N = 2^11 .. 2^15)
-//   F64 : q < 2^62, 64-bit residues  (FHE_WIDTH_64, N = 2^11 .. 2^14)
+//   F32 : q < 2^30, 32-bit residues, Harvey/Shoup integer butterflies          (FHE_WIDTH_32, N = 2^11 .. 2^15)
+//   F52 : q < 2^43, residues held as exact integers in doubles, FMA butterflies (FHE_WIDTH_52, N = 2^11 .. 2^14)
+//   F64 : q < 2^62, 64-bit residues, Harvey/Shoup integer butterflies           (FHE_WIDTH_64, N = 2^11 .. 2^14)
 //
 // Replaces ntt_forward_optimized_kernel / ntt_inverse_optimized_kernel / ntt_pointwise_mul_kernel /
 // bit_reverse_kernel / ntt_forward_batch_kernel (kernels/ntt_kernels.cu:7-210) and the
@@ -31,12 +32,59 @@ typedef uint32_t v4u32 __attribute__((ext_vector_type(4)));   // native vectors:
 typedef uint64_t v2u64 __attribute__((ext_vector_type(2)));
 
 // ---- field traits ---------------------------------------------------------------------------------------
-struct F32 {
-    using E = uint32_t;                 // residue
-    using TW = uint2;                   // (w, floor(w * 2^32 / q))
+// A field supplies the residue type E, the twiddle record TW = (w, companion), the butterflies and the
+// range bookkeeping.  "lazy" ranges: integer fields keep forward values in [0,4q) and inverse values in [0,2q);
+// the floating-point field keeps signed values whose magnitude stays far below 2^53.
+template <class E>
+__device__ __forceinline__ E csub(E x, E c) {   // x - (x >= c ? c : 0) for unsigned E
+    E d = x - c;
+    return d < x ? d : x;                       // sub + unsigned min (d wraps above x exactly when x < c)
+}
+
+template <class Self, class E_, class TW_>
+struct IntField {
+    using E = E_;
+    using TW = TW_;
+    // Harvey lazy Cooley-Tukey butterfly, inputs and outputs in [0,4q)
+    __device__ static __forceinline__ void fwd_bfly(E &x0, E &x1, const TW &w, E q, E q2) {
+        E X = csub<E>(x0, q2);
+        E T = Self::shoup_mul(x1, w.x, w.y, q);
+        x0 = X + T;
+        x1 = X - T + q2;
+    }
+    // Harvey lazy Gentleman-Sande butterfly, inputs and outputs in [0,2q)
+    __device__ static __forceinline__ void inv_bfly(E &x0, E &x1, const TW &w, E q, E q2) {
+        E X = x0, Y = x1;
+        x0 = csub<E>(X + Y, q2);
+        x1 = Self::shoup_mul(X - Y + q2, w.x, w.y, q);
+    }
+    // last inverse stage with the n^-1 scaling folded in (outputs in [0,2q))
+    __device__ static __forceinline__ void inv_last(E &x0, E &x1, E q, E q2, E ninv, E ninv_s, E ninvw, E ninvw_s) {
+        E X = x0, Y = x1;
+        x0 = Self::shoup_mul(X + Y, ninv, ninv_s, q);
+        x1 = Self::shoup_mul(X - Y + q2, ninvw, ninvw_s, q);
+    }
+    __device__ static __forceinline__ void regroup(E (&)[32], E, E) {}                       // integer ranges never grow
+    __device__ static __forceinline__ E canon_fwd(E x, E q, E q2, E) { return csub<E>(csub<E>(x, q2), q); }   // [0,4q) -> [0,q)
+    __device__ static __forceinline__ E canon_inv(E x, E q) { return csub<E>(x, q); }       // [0,2q) -> [0,q)
+    // NTT-domain product for the fused kernels: a canonical, b lazy (< 4q); result in (0,2q), carries 2^-W
+    __device__ static __forceinline__ E pw_mul(E a, E b, E q, E qinv) { return Self::mont_mul(a, b, q, qinv); }
+    // (0,2q)+(0,2q) -> [0,2q)
+    __device__ static __forceinline__ E pw_add(E a, E b, E, E q2) { return csub<E>(a + b, q2); }
+    // element-wise canonical ops
+    template <class L> __device__ static __forceinline__ E ew_mul(E x, E y, const L &P) {
+        return csub<E>(Self::shoup_mul(Self::mont_mul(x, y, P.q, P.qinv), P.r1, P.r1_s, P.q), P.q);
+    }
+    __device__ static __forceinline__ E ew_add(E x, E y, E q) { return csub<E>(x + y, q); }
+    __device__ static __forceinline__ E ew_sub(E x, E y, E q) { return csub<E>(x - y + q, q); }
+    __device__ static __forceinline__ bool ge(uint64_t raw, E q) { return raw >= (uint64_t)q; }
+};
+
+struct F32 : IntField<F32, uint32_t, uint2> {
     using V16 = v4u32;                  // one 16-byte half container
     static constexpr int MAX_LOGN = 15;
-    // x*w mod q for w < q with companion ws; any x; result in [0, 2q).
+    static constexpr int MULT_MINW = 4; // waves per SIMD the fused multiply is compiled for (4 workgroups per CU at N = 8192)
+    // x*w mod q for w < q with companion ws = floor(w*2^32/q); any x; result in [0, 2q).
     __device__ static __forceinline__ E shoup_mul(E x, E w, E ws, E q) { return x * w - __umulhi(x, ws) * q; }
     // a*b*2^-32 mod q, a*b < q*2^32; result in (0, 2q).
     __device__ static __forceinline__ E mont_mul(E a, E b, E q, E qinv) {
@@ -46,15 +94,14 @@ struct F32 {
     }
     __device__ static __forceinline__ E load_low(const void *container) { return __builtin_nontemporal_load((const E *)container); }
     __device__ static __forceinline__ V16 pack(E v) { V16 o = {v, 0u, 0u, 0u}; return o; }
-    __device__ static __forceinline__ E low(const V16 &v) { return v.x; }
+    __device__ static __forceinline__ uint64_t low(const V16 &v) { return v.x; }
     __device__ static __forceinline__ bool upper_nonzero(const V16 &v) { return (v.y | v.z | v.w) != 0; }
     __device__ static __forceinline__ bool any_nonzero(const V16 &v) { return (v.x | v.y | v.z | v.w) != 0; }
 };
-struct F64 {
-    using E = uint64_t;
-    using TW = ulonglong2;              // (w, floor(w * 2^64 / q))
+struct F64 : IntField<F64, uint64_t, ulonglong2> {
     using V16 = v2u64;
     static constexpr int MAX_LOGN = 14; // 2^15 x 8 B does not fit the 160 KiB LDS
+    static constexpr int MULT_MINW = 2;
     __device__ static __forceinline__ E shoup_mul(E x, E w, E ws, E q) { return x * w - __umul64hi(x, ws) * q; }
     __device__ static __forceinline__ E mont_mul(E a, E b, E q, E qinv) {
         E lo = a * b, hi = __umul64hi(a, b);
@@ -63,16 +110,83 @@ struct F64 {
     }
     __device__ static __forceinline__ E load_low(const void *container) { return __builtin_nontemporal_load((const E *)container); }
     __device__ static __forceinline__ V16 pack(E v) { V16 o = {v, 0ull}; return o; }
-    __device__ static __forceinline__ E low(const V16 &v) { return v.x; }
+    __device__ static __forceinline__ uint64_t low(const V16 &v) { return v.x; }
     __device__ static __forceinline__ bool upper_nonzero(const V16 &v) { return v.y != 0; }
     __device__ static __forceinline__ bool any_nonzero(const V16 &v) { return (v.x | v.y) != 0; }
+};
+
+// Residues as exact integers in IEEE doubles (q < 2^43).  x*w mod q with the precomputed companion wq = fl(w/q):
+//   h = fl(x*w), l = x*w - h (exact, one FMA), c = rint(fl(x*wq)), d = h - c*q (exact, one FMA), r = d + l.
+// For |x| < 2^49: |fl(x*wq) - x*w/q| < 2^-2, so c is within 1 of the nearest integer and |r| < 0.76 q; h - c*q and l are
+// integers below 2^53 in magnitude, hence every step is exact and r == x*w (mod q).  Six half-rate FP64 instructions
+// replace the ~20 half-rate 32-bit integer multiplies of a 64-bit Shoup product (measured 4.5 vs 63+ cycles per wave).
+// Butterfly outputs are not range-reduced: forward values grow by < 0.76 q per stage (<= 12 q after 14 stages), inverse
+// values are brought back below 0.76 q once per 5-stage register group (regroup).
+struct F52 {
+    using E = double;
+    using TW = double2;                 // (w, fl(w / q))
+    using V16 = v2u64;
+    static constexpr int MAX_LOGN = 14;
+    static constexpr int MULT_MINW = 2;
+    __device__ static __forceinline__ E mulmod(E x, E w, E wq, E q) {
+#pragma clang fp contract(off)
+        E h = x * w;
+        E l = __builtin_fma(x, w, -h);
+        E c = __builtin_rint(x * wq);
+        E d = __builtin_fma(-c, q, h);
+        return d + l;
+    }
+    __device__ static __forceinline__ E reduce(E x, E q, E qinv) {       // |x| < 2^49 -> |r| < 0.76 q
+#pragma clang fp contract(off)
+        E c = __builtin_rint(x * qinv);
+        return __builtin_fma(-c, q, x);
+    }
+    __device__ static __forceinline__ void fwd_bfly(E &x0, E &x1, const TW &w, E q, E) {
+        E T = mulmod(x1, w.x, w.y, q);
+        x1 = x0 - T;
+        x0 = x0 + T;
+    }
+    __device__ static __forceinline__ void inv_bfly(E &x0, E &x1, const TW &w, E q, E) {
+        E S = x0 + x1, D = x0 - x1;
+        x0 = S;
+        x1 = mulmod(D, w.x, w.y, q);
+    }
+    __device__ static __forceinline__ void inv_last(E &x0, E &x1, E q, E, E ninv, E ninv_s, E ninvw, E ninvw_s) {
+        E S = x0 + x1, D = x0 - x1;
+        x0 = mulmod(S, ninv, ninv_s, q);
+        x1 = mulmod(D, ninvw, ninvw_s, q);
+    }
+    __device__ static __forceinline__ void regroup(E (&x)[32], E q, E qinv) {
+#pragma unroll
+        for (int r = 0; r < 32; r++) x[r] = reduce(x[r], q, qinv);
+    }
+    __device__ static __forceinline__ E canon_fwd(E x, E q, E, E qinv) { E r = reduce(x, q, qinv); return r < 0 ? r + q : r; }
+    __device__ static __forceinline__ E canon_inv(E x, E q) { return x < 0 ? x + q : x; }   // |x| < 0.76 q
+    __device__ static __forceinline__ E pw_mul(E a, E b, E q, E qinv) {                     // a in [0,q), |b| < 2^48
+#pragma clang fp contract(off)
+        E h = a * b;
+        E l = __builtin_fma(a, b, -h);
+        E c = __builtin_rint(h * qinv);
+        E d = __builtin_fma(-c, q, h);
+        return d + l;
+    }
+    __device__ static __forceinline__ E pw_add(E a, E b, E, E) { return a + b; }
+    template <class L> __device__ static __forceinline__ E ew_mul(E x, E y, const L &P) { return canon_inv(pw_mul(x, y, P.q, P.qinv), P.q); }
+    __device__ static __forceinline__ E ew_add(E x, E y, E q) { E t = x + y; return t >= q ? t - q : t; }
+    __device__ static __forceinline__ E ew_sub(E x, E y, E q) { E t = x - y; return t < 0 ? t + q : t; }
+    __device__ static __forceinline__ E load_low(const void *container) { return (E)__builtin_nontemporal_load((const uint64_t *)container); }
+    __device__ static __forceinline__ V16 pack(E v) { V16 o = {(uint64_t)v, 0ull}; return o; }
+    __device__ static __forceinline__ uint64_t low(const V16 &v) { return v.x; }
+    __device__ static __forceinline__ bool upper_nonzero(const V16 &v) { return v.y != 0; }
+    __device__ static __forceinline__ bool any_nonzero(const V16 &v) { return (v.x | v.y) != 0; }
+    __device__ static __forceinline__ bool ge(uint64_t raw, E q) { return (E)raw >= q; }
 };
 
 // Per-limb constants (device memory, one entry per RNS prime).  *_s = Shoup companion floor(x*2^W/q).
 template <class F>
 struct Limb {
     using E = typename F::E;
-    E q, q2, qinv, _pad0;                 // qinv = q^-1 mod 2^W
+    E q, q2, qinv, _pad0;                 // qinv = q^-1 mod 2^W   (F52: fl(1/q))
     E r1, r1_s;                           // 2^W mod q             (undo the 2^-W of mont_mul in `pointwise`)
     E ninv, ninv_s;                       // n^-1
     E ninvw, ninvw_s;                     // n^-1 * itw[1]
@@ -83,13 +197,7 @@ struct Limb {
 };
 using Limb32 = Limb<F32>;
 using Limb64 = Limb<F64>;
-
-// x - (x >= c ? c : 0)
-template <class E>
-__device__ __forceinline__ E csub(E x, E c) {
-    E d = x - c;
-    return d < x ? d : x;      // sub + unsigned min (d wraps above x exactly when x < c)
-}
+using Limb52 = Limb<F52>;
 
 template <int LOGN>
 struct NttCfg {
@@ -170,10 +278,7 @@ __device__ __forceinline__ void fwd_stages(typename F::E (&x)[32], uint32_t tid,
         for (int r = 0; r < 32; r++) {
             if (r & (1 << k)) continue;
             const typename F::TW w = p[Pat::off(r) >> (b + 1)];
-            E X = csub<E>(x[r], q2);
-            E Tt = F::shoup_mul(x[r | (1 << k)], w.x, w.y, q);
-            x[r] = X + Tt;
-            x[r | (1 << k)] = X - Tt + q2;
+            F::fwd_bfly(x[r], x[r | (1 << k)], w, q, q2);
         }
     }
 }
@@ -192,9 +297,7 @@ __device__ __forceinline__ void inv_stages(typename F::E (&x)[32], uint32_t tid,
         for (int r = 0; r < 32; r++) {
             if (r & (1 << k)) continue;
             const typename F::TW w = p[Pat::off(r) >> (b + 1)];
-            E X = x[r], Y = x[r | (1 << k)];
-            x[r] = csub<E>(X + Y, q2);
-            x[r | (1 << k)] = F::shoup_mul(X - Y + q2, w.x, w.y, q);
+            F::inv_bfly(x[r], x[r | (1 << k)], w, q, q2);
         }
     }
 }
@@ -204,11 +307,7 @@ __device__ __forceinline__ void inv_last_stage(typename F::E (&x)[32], typename 
                                                typename F::E ninv_s, typename F::E ninvw, typename F::E ninvw_s) {
     using E = typename F::E;
 #pragma unroll
-    for (int r = 0; r < 16; r++) {
-        E X = x[r], Y = x[r | 16];
-        x[r] = F::shoup_mul(X + Y, ninv, ninv_s, q);
-        x[r | 16] = F::shoup_mul(X - Y + q2, ninvw, ninvw_s, q);
-    }
+    for (int r = 0; r < 16; r++) F::inv_last(x[r], x[r | 16], q, q2, ninv, ninv_s, ninvw, ninvw_s);
 }
 
 // ---- global memory <-> registers ----------------------------------------------------------------------
@@ -257,10 +356,12 @@ __device__ __forceinline__ void inv_core(typename F::E (&x)[32], typename F::E *
                                          typename F::E ninv, typename F::E ninv_s, typename F::E ninvw, typename F::E ninvw_s) {
     using C = NttCfg<LOGN>;
     inv_stages<F, LOGN, PatZ<LOGN>, 0, 4>(x, tid, P.itw, P.q, P.q2);
+    F::regroup(x, P.q, P.qinv);
     lds_put<PatZ<LOGN>>(lds, tid, x);
     __syncthreads();
     lds_get<PatY<LOGN>>(lds, tid, x);
     inv_stages<F, LOGN, PatY<LOGN>, 0, 4>(x, tid, P.itw, P.q, P.q2);
+    F::regroup(x, P.q, P.qinv);
     lds_put<PatY<LOGN>>(lds, tid, x);
     __syncthreads();
     lds_get<PatA<LOGN>>(lds, tid, x);
@@ -285,7 +386,7 @@ ntt_forward_kernel(char *__restrict__ data, const Limb<F> *__restrict__ limbs, u
     load_A<F, LOGN>(poly, tid, x);
     fwd_core<F, LOGN>(x, lds, tid, P);
 #pragma unroll
-    for (int r = 0; r < 32; r++) x[r] = csub<E>(csub<E>(x[r], P.q2), P.q);
+    for (int r = 0; r < 32; r++) x[r] = F::canon_fwd(x[r], P.q, P.q2, P.qinv);
     lds_put<PatZ<LOGN>>(lds, tid, x);      // the slots this thread read last: no barrier needed before
     __syncthreads();
     store_from_lds<F, LOGN>(poly, lds, tid);
@@ -307,7 +408,7 @@ ntt_inverse_kernel(char *__restrict__ data, const Limb<F> *__restrict__ limbs, u
     lds_get<PatZ<LOGN>>(lds, tid, x);
     inv_core<F, LOGN>(x, lds, tid, P, P.ninv, P.ninv_s, P.ninvw, P.ninvw_s);
 #pragma unroll
-    for (int r = 0; r < 32; r++) x[r] = csub<E>(x[r], P.q);
+    for (int r = 0; r < 32; r++) x[r] = F::canon_inv(x[r], P.q);
     lds_put<PatA<LOGN>>(lds, tid, x);
     __syncthreads();
     store_from_lds<F, LOGN>(poly, lds, tid);
@@ -329,14 +430,14 @@ ntt_multiply_kernel(char *__restrict__ res, const char *__restrict__ a, const ch
     load_A<F, LOGN>(b + off, tid, y);      // issued before a's butterflies: b's HBM latency hides under them
     fwd_core<F, LOGN>(x, lds, tid, P);
 #pragma unroll
-    for (int r = 0; r < 32; r++) x[r] = csub<E>(csub<E>(x[r], P.q2), P.q);   // canonical: keeps x*y < q*2^W
+    for (int r = 0; r < 32; r++) x[r] = F::canon_fwd(x[r], P.q, P.q2, P.qinv);   // canonical: keeps x*y < q*2^W
     __syncthreads();                       // all Z-pattern reads of a are done before b overwrites the slots
     fwd_core<F, LOGN>(y, lds, tid, P);
 #pragma unroll
-    for (int r = 0; r < 32; r++) x[r] = F::mont_mul(x[r], y[r], P.q, P.qinv);   // (0,2q), carries 2^-W
+    for (int r = 0; r < 32; r++) x[r] = F::pw_mul(x[r], y[r], P.q, P.qinv);   // (0,2q), carries 2^-W
     inv_core<F, LOGN>(x, lds, tid, P, P.ninv_r, P.ninv_r_s, P.ninvw_r, P.ninvw_r_s);
 #pragma unroll
-    for (int r = 0; r < 32; r++) x[r] = csub<E>(x[r], P.q);
+    for (int r = 0; r < 32; r++) x[r] = F::canon_inv(x[r], P.q);
     lds_put<PatA<LOGN>>(lds, tid, x);
     __syncthreads();
     store_from_lds<F, LOGN>(res + off, lds, tid);
@@ -368,14 +469,14 @@ ntt_multiply_persistent_kernel(char *__restrict__ res, const char *__restrict__ 
         const Limb<F> P = limbs[p % L];
         fwd_core<F, LOGN>(x, lds, tid, P);
 #pragma unroll
-        for (int r = 0; r < 32; r++) x[r] = csub<E>(csub<E>(x[r], P.q2), P.q);
+        for (int r = 0; r < 32; r++) x[r] = F::canon_fwd(x[r], P.q, P.q2, P.qinv);
         __syncthreads();
         fwd_core<F, LOGN>(y, lds, tid, P);
 #pragma unroll
-        for (int r = 0; r < 32; r++) x[r] = F::mont_mul(x[r], y[r], P.q, P.qinv);
+        for (int r = 0; r < 32; r++) x[r] = F::pw_mul(x[r], y[r], P.q, P.qinv);
         inv_core<F, LOGN>(x, lds, tid, P, P.ninv_r, P.ninv_r_s, P.ninvw_r, P.ninvw_r_s);
 #pragma unroll
-        for (int r = 0; r < 32; r++) x[r] = csub<E>(x[r], P.q);
+        for (int r = 0; r < 32; r++) x[r] = F::canon_inv(x[r], P.q);
         lds_put<PatA<LOGN>>(lds, tid, x);
         __syncthreads();
         store_from_lds<F, LOGN>(res + (size_t)p * (C::N * 32), lds, tid);
@@ -415,33 +516,33 @@ ntt_ct_multiply_kernel(char *__restrict__ c0, char *__restrict__ c1, char *__res
     fwd_core<F, LOGN>(B1, lds, tid, P);
 #pragma unroll
     for (int r = 0; r < 32; r++) {
-        E u0 = csub<E>(csub<E>(A0[r], P.q2), P.q), u1 = csub<E>(csub<E>(A1[r], P.q2), P.q);   // canonical a-side
+        E u0 = F::canon_fwd(A0[r], P.q, P.q2, P.qinv), u1 = F::canon_fwd(A1[r], P.q, P.q2, P.qinv);   // canonical a-side
         E v0 = B0[r], v1 = B1[r];                                                             // lazy b-side (< 4q)
-        E t00 = F::mont_mul(u0, v0, P.q, P.qinv);
-        E t01 = F::mont_mul(u0, v1, P.q, P.qinv);
-        E t10 = F::mont_mul(u1, v0, P.q, P.qinv);
-        E t11 = F::mont_mul(u1, v1, P.q, P.qinv);
+        E t00 = F::pw_mul(u0, v0, P.q, P.qinv);
+        E t01 = F::pw_mul(u0, v1, P.q, P.qinv);
+        E t10 = F::pw_mul(u1, v0, P.q, P.qinv);
+        E t11 = F::pw_mul(u1, v1, P.q, P.qinv);
         A0[r] = t00;                           // (0,2q)
-        A1[r] = csub<E>(t01 + t10, P.q2);      // (0,4q) -> [0,2q)
+        A1[r] = F::pw_add(t01, t10, P.q, P.q2);   // (0,4q) -> [0,2q)
         B0[r] = t11;
     }
     inv_core<F, LOGN>(A0, lds, tid, P, P.ninv_r, P.ninv_r_s, P.ninvw_r, P.ninvw_r_s);
 #pragma unroll
-    for (int r = 0; r < 32; r++) A0[r] = csub<E>(A0[r], P.q);
+    for (int r = 0; r < 32; r++) A0[r] = F::canon_inv(A0[r], P.q);
     lds_put<PatA<LOGN>>(lds, tid, A0);
     __syncthreads();
     store_from_lds<F, LOGN>(c0 + off, lds, tid);
     __syncthreads();
     inv_core<F, LOGN>(A1, lds, tid, P, P.ninv_r, P.ninv_r_s, P.ninvw_r, P.ninvw_r_s);
 #pragma unroll
-    for (int r = 0; r < 32; r++) A1[r] = csub<E>(A1[r], P.q);
+    for (int r = 0; r < 32; r++) A1[r] = F::canon_inv(A1[r], P.q);
     lds_put<PatA<LOGN>>(lds, tid, A1);
     __syncthreads();
     store_from_lds<F, LOGN>(c1 + off, lds, tid);
     __syncthreads();
     inv_core<F, LOGN>(B0, lds, tid, P, P.ninv_r, P.ninv_r_s, P.ninvw_r, P.ninvw_r_s);
 #pragma unroll
-    for (int r = 0; r < 32; r++) B0[r] = csub<E>(B0[r], P.q);
+    for (int r = 0; r < 32; r++) B0[r] = F::canon_inv(B0[r], P.q);
     lds_put<PatA<LOGN>>(lds, tid, B0);
     __syncthreads();
     store_from_lds<F, LOGN>(c2 + off, lds, tid);
@@ -460,9 +561,9 @@ ew_kernel(typename F::V16 *__restrict__ r, const typename F::V16 *__restrict__ a
         if (!(g & 1)) {
             const Limb<F> &P = limbs[(uint32_t)((g >> (log_n + 1)) % L)];
             E x = F::load_low(a + g), y = F::load_low(b + g), q = P.q;
-            if (OP == 0) o = csub<E>(F::shoup_mul(F::mont_mul(x, y, q, P.qinv), P.r1, P.r1_s, q), q);
-            else if (OP == 1) o = csub<E>(x + y, q);
-            else o = csub<E>(x - y + q, q);
+            if (OP == 0) o = F::ew_mul(x, y, P);
+            else if (OP == 1) o = F::ew_add(x, y, q);
+            else o = F::ew_sub(x, y, q);
         }
         __builtin_nontemporal_store(F::pack(o), r + g);
     }
@@ -478,7 +579,7 @@ check_kernel(const typename F::V16 *__restrict__ a, const Limb<F> *__restrict__ 
     for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < halves; g += stride) {
         typename F::V16 v = a[g];
         if (g & 1) bad |= F::any_nonzero(v);
-        else bad |= F::upper_nonzero(v) || F::low(v) >= limbs[(uint32_t)((g >> (log_n + 1)) % L)].q;
+        else bad |= F::upper_nonzero(v) || F::ge(F::low(v), limbs[(uint32_t)((g >> (log_n + 1)) % L)].q);
     }
     if (bad) atomicOr(flag, 1u);
 }

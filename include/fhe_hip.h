@@ -50,6 +50,7 @@ typedef enum fhe_status {
 typedef enum fhe_width_class {
     FHE_WIDTH_32 = 1,    /* every q < 2^30 : 32-bit lazy Shoup butterflies, whole NTT in LDS */
     FHE_WIDTH_64 = 2,    /* every q < 2^62 : 64-bit lazy butterflies, whole NTT in LDS */
+    FHE_WIDTH_52 = 3,    /* every q < 2^43 : residues as exact integers in doubles, FP64 FMA butterflies, whole NTT in LDS */
     FHE_WIDTH_256 = 4    /* anything else < 2^255 : full 4x64-bit Montgomery (R = 2^256), multi-pass */
 } fhe_width_class;
 

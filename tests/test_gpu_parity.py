@@ -76,7 +76,10 @@ CASES = [
     (32768, ("bits", 30, 1), 2, 1),
     (2048, ("bits", 60, 2), 2, 2),
     (8192, ("bits", 60, 2), 2, 2),
-    (16384, ("bits", 40, 6), 1, 2),             # BASELINE config 4 shape (40-bit primes)
+    (16384, ("bits", 40, 6), 1, 3),             # BASELINE config 4 shape (40-bit primes) -> FP64-FMA path
+    (8192, ("bits", 43, 2), 2, 3),              # widest primes the FP64 path accepts
+    (2048, ("bits", 31, 2), 2, 3),              # just above the 32-bit path
+    (4096, ("bits", 44, 1), 1, 2),              # just above the FP64 path -> 64-bit integer path
     (8192, ("bits", 64, 1), 1, 4),              # 64-bit prime: too wide for the lazy 64-bit path
     (65536, ("bits", 30, 1), 1, 4),             # larger than LDS: general path
 ]
@@ -132,7 +135,7 @@ def test_forward_inverse_multiply_match_oracle(eng, oracle, n, spec, batch, widt
 
 
 @pytest.mark.parametrize("n,spec,batch", [(2048, [40961], 2), (8192, ("bits", 30, 4), 2), (4096, ("bits", 60, 2), 1),
-                                          (256, ("bits", 250, 2), 1)])
+                                          (16384, ("bits", 40, 6), 1), (256, ("bits", 250, 2), 1)])
 def test_ct_multiply_matches_oracle(eng, oracle, n, spec, batch):
     """FHEContext::multiply tensor product (src/fhe.cu:199-218)."""
     moduli = _moduli(spec, n)
@@ -165,6 +168,49 @@ def test_single_modulus_engine_reference_scenarios(eng, oracle):
     e2.multiply(dR, dA, dB)
     p = oracle.Plan(2048, 40961)
     assert np.array_equal(dR.download(), p.schoolbook(a, b))
+
+
+@pytest.mark.parametrize("force,width", [("64", 2), ("256", 4)])
+def test_forced_wider_paths_agree(eng, oracle, monkeypatch, force, width):
+    """The same 40-bit basis through the 64-bit integer path and the full-width path (FHE_HIP_FORCE_WIDTH)."""
+    n = 4096; moduli = nm.ntt_primes(40, n, 2); batch = 2
+    monkeypatch.setenv("FHE_HIP_FORCE_WIDTH", force)
+    e = eng.RnsNttEngine(n, moduli)
+    assert e.width_class == width
+    rp = oracle.RnsPlan(n, moduli)
+    a = rns_poly(31, moduli, n, batch); b = rns_poly(32, moduli, n, batch)
+    dA, dB, dR = _up(eng, a), _up(eng, b), eng.DeviceBuffer(a.nbytes)
+    e.multiply(dR, dA, dB, batch)
+    assert np.array_equal(dR.download(a.shape), rp.polymul(a, b, threads=8))
+    e.forward(dA, batch)
+    assert np.array_equal(dA.download(a.shape), rp.forward(a, threads=8))
+
+
+@pytest.mark.parametrize("n,bits,L", [(8192, 30, 2), (8192, 43, 2), (16384, 40, 2), (8192, 62, 1), (2048, 30, 1)])
+def test_extreme_value_polynomials(eng, oracle, n, bits, L):
+    """Worst-case magnitudes for the lazy / floating-point ranges: every coefficient q-1, alternating 0 / q-1,
+    and q-1 against random (forward, inverse, fused multiply, tensor product)."""
+    moduli = nm.ntt_primes(bits, n, L)
+    e = eng.RnsNttEngine(n, moduli); rp = oracle.RnsPlan(n, moduli)
+    top = np.zeros((1, L, n, 4), np.uint64); alt = top.copy()
+    for l, q in enumerate(moduli):
+        top[0, l, :, 0] = q - 1
+        alt[0, l, ::2, 0] = q - 1
+    rnd = rns_poly(41, moduli, n, 1)
+    dR = eng.DeviceBuffer(top.nbytes)
+    for x in (top, alt):
+        d = _up(eng, x); e.forward(d, 1)
+        assert np.array_equal(d.download(top.shape), rp.forward(x, threads=8))
+        d = _up(eng, x); e.inverse(d, 1)
+        assert np.array_equal(d.download(top.shape), rp.inverse(x, threads=8))
+    for x, y in ((top, top), (top, alt), (alt, rnd), (top, rnd)):
+        e.multiply(dR, _up(eng, x), _up(eng, y), 1)
+        assert np.array_equal(dR.download(top.shape), rp.polymul(x, y, threads=8))
+    c = [eng.DeviceBuffer(top.nbytes) for _ in range(3)]
+    e.ct_multiply(c[0], c[1], c[2], _up(eng, top), _up(eng, alt), _up(eng, top), _up(eng, rnd), 1)
+    w = rp.ct_multiply(top, alt, top, rnd, threads=8)
+    for got, want in zip(c, w):
+        assert np.array_equal(got.download(top.shape), want)
 
 
 # ------------------------------------------------------------------------------------ edge cases
