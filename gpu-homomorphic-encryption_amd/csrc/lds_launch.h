@@ -8,6 +8,10 @@ namespace fhe_dev {
 
 enum LdsOp { LDS_FORWARD = 0, LDS_INVERSE = 1, LDS_MULTIPLY = 2, LDS_CT_MULTIPLY = 3 };
 
+// true when the instance runs the tensor product as one fused launch; otherwise LDS_CT_MULTIPLY issues
+// multiply(c0), multiply(c2) and the two-product kernel for c1 (three launches, 11*S instead of 7*S bytes)
+constexpr bool lds_ct_fused(int elem_bytes, int log_n) { return elem_bytes == 4 || log_n <= 13; }
+
 struct LdsArgs {
     int op;
     void *r0, *r1, *r2;                  // outputs (forward / inverse: r0 is the in-place buffer)

@@ -268,7 +268,6 @@ __device__ __forceinline__ void lds_get(const E *lds, uint32_t tid, E (&x)[32]) 
 template <class F, int LOGN, class Pat, int KHI, int KLO>
 __device__ __forceinline__ void fwd_stages(typename F::E (&x)[32], uint32_t tid, const typename F::TW *__restrict__ tw,
                                            typename F::E q, typename F::E q2) {
-    using E = typename F::E;
     const uint32_t base = Pat::TW_UNIFORM ? 0u : Pat::base(tid);   // uniform -> scalar twiddle loads
 #pragma unroll
     for (int k = KHI; k >= KLO; k--) {
@@ -287,7 +286,6 @@ __device__ __forceinline__ void fwd_stages(typename F::E (&x)[32], uint32_t tid,
 template <class F, int LOGN, class Pat, int KLO, int KHI>
 __device__ __forceinline__ void inv_stages(typename F::E (&x)[32], uint32_t tid, const typename F::TW *__restrict__ itw,
                                            typename F::E q, typename F::E q2) {
-    using E = typename F::E;
     const uint32_t base = Pat::TW_UNIFORM ? 0u : Pat::base(tid);
 #pragma unroll
     for (int k = KLO; k <= KHI; k++) {
@@ -305,7 +303,6 @@ __device__ __forceinline__ void inv_stages(typename F::E (&x)[32], uint32_t tid,
 template <class F>
 __device__ __forceinline__ void inv_last_stage(typename F::E (&x)[32], typename F::E q, typename F::E q2, typename F::E ninv,
                                                typename F::E ninv_s, typename F::E ninvw, typename F::E ninvw_s) {
-    using E = typename F::E;
 #pragma unroll
     for (int r = 0; r < 16; r++) F::inv_last(x[r], x[r | 16], q, q2, ninv, ninv_s, ninvw, ninvw_s);
 }
@@ -439,6 +436,47 @@ ntt_multiply_kernel(char *__restrict__ res, const char *__restrict__ a, const ch
 #pragma unroll
     for (int r = 0; r < 32; r++) x[r] = F::canon_inv(x[r], P.q);
     lds_put<PatA<LOGN>>(lds, tid, x);
+    __syncthreads();
+    store_from_lds<F, LOGN>(res + off, lds, tid);
+}
+
+// r = a0 (*) b1 + a1 (*) b0 in one launch (the c1 term of the tensor product) for configurations whose four
+// transformed operands do not fit the register file (8-byte residues at N = 2^14): at most three arrays are live.
+// HBM traffic = read 4 polynomials + write 1.
+template <class F, int LOGN, int MINW = 1>
+__global__ void __launch_bounds__(NttCfg<LOGN>::T, MINW)
+ntt_mac2_kernel(char *__restrict__ res, const char *__restrict__ a0, const char *__restrict__ b1,
+                const char *__restrict__ a1, const char *__restrict__ b0, const Limb<F> *__restrict__ limbs, uint32_t L) {
+    using C = NttCfg<LOGN>;
+    using E = typename F::E;
+    __shared__ E lds[C::LDS_ELEMS];
+    const uint32_t tid = threadIdx.x, p = blockIdx.x;
+    const Limb<F> P = limbs[p % L];
+    const size_t off = (size_t)p * (C::N * 32);
+    E x[32], y[32], acc[32];
+    load_A<F, LOGN>(a0 + off, tid, x);
+    load_A<F, LOGN>(b1 + off, tid, y);
+    fwd_core<F, LOGN>(x, lds, tid, P);
+#pragma unroll
+    for (int r = 0; r < 32; r++) x[r] = F::canon_fwd(x[r], P.q, P.q2, P.qinv);
+    __syncthreads();
+    fwd_core<F, LOGN>(y, lds, tid, P);
+#pragma unroll
+    for (int r = 0; r < 32; r++) acc[r] = F::pw_mul(x[r], y[r], P.q, P.qinv);
+    load_A<F, LOGN>(a1 + off, tid, x);
+    load_A<F, LOGN>(b0 + off, tid, y);
+    __syncthreads();
+    fwd_core<F, LOGN>(x, lds, tid, P);
+#pragma unroll
+    for (int r = 0; r < 32; r++) x[r] = F::canon_fwd(x[r], P.q, P.q2, P.qinv);
+    __syncthreads();
+    fwd_core<F, LOGN>(y, lds, tid, P);
+#pragma unroll
+    for (int r = 0; r < 32; r++) acc[r] = F::pw_add(acc[r], F::pw_mul(x[r], y[r], P.q, P.qinv), P.q, P.q2);
+    inv_core<F, LOGN>(acc, lds, tid, P, P.ninv_r, P.ninv_r_s, P.ninvw_r, P.ninvw_r_s);
+#pragma unroll
+    for (int r = 0; r < 32; r++) acc[r] = F::canon_inv(acc[r], P.q);
+    lds_put<PatA<LOGN>>(lds, tid, acc);
     __syncthreads();
     store_from_lds<F, LOGN>(res + off, lds, tid);
 }
