@@ -73,6 +73,10 @@ def lib():
         "fhe_rns_poly_sub": ([vp, vp, vp, vp, u32], ci),
         "fhe_ct_multiply": ([vp] * 8 + [u32], ci),
         "fhe_rns_check_canonical": ([vp, vp, u32], ci),
+        "fhe_relin_num_digits": ([vp, u32, P(u32)], ci),
+        "fhe_relin_keys_create": ([vp, P(vp), u32, P(vp), P(vp), u32], ci),
+        "fhe_relin_keys_destroy": ([vp], ci),
+        "fhe_ct_relinearize": ([vp, vp, vp, vp, vp, u32], ci),
         "fhe_timer_create": ([P(vp)], ci),
         "fhe_timer_destroy": ([vp], ci),
         "fhe_rns_timer_start": ([vp, vp], ci),
@@ -276,12 +280,43 @@ class RnsNttEngine:
         _check(lib().fhe_ct_multiply(self.h, _ptr(d_c0), _ptr(d_c1), _ptr(d_c2), _ptr(d_a0), _ptr(d_a1), _ptr(d_b0),
                                      _ptr(d_b1), batch))
 
+    def relin_num_digits(self, decomp_bits):
+        k = ctypes.c_uint32(0); _check(lib().fhe_relin_num_digits(self.h, decomp_bits, ctypes.byref(k))); return k.value
+
+    def import_relin_keys(self, decomp_bits, keys_b, keys_a):
+        """keys_b / keys_a: lists of device buffers, each an [L][n] polynomial in coefficient form."""
+        n = len(keys_b)
+        pb = (ctypes.c_void_p * n)(*[_ptr(k) for k in keys_b]); pa = (ctypes.c_void_p * n)(*[_ptr(k) for k in keys_a])
+        out = ctypes.c_void_p()
+        _check(lib().fhe_relin_keys_create(self.h, ctypes.byref(out), decomp_bits, pb, pa, n))
+        return RelinKeys(out)
+
+    def relinearize(self, rk, d_c0, d_c1, d_c2, batch=1):
+        _check(lib().fhe_ct_relinearize(self.h, rk.h, _ptr(d_c0), _ptr(d_c1), _ptr(d_c2), batch))
+
     def check_canonical(self, d_data, batch=1):
         _check(lib().fhe_rns_check_canonical(self.h, _ptr(d_data), batch))
 
     def close(self):
         if self.h:
             lib().fhe_rns_ntt_destroy(self.h); self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class RelinKeys:
+    """Relinearisation keys imported into an engine (NTT-domain copies owned by the library)."""
+
+    def __init__(self, h):
+        self.h = h
+
+    def close(self):
+        if self.h:
+            lib().fhe_relin_keys_destroy(self.h); self.h = None
 
     def __del__(self):
         try:

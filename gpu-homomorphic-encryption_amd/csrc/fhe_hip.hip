@@ -579,6 +579,125 @@ extern "C" int fhe_rns_check_canonical(fhe_rns_ntt_t *h, const void *d_data, uin
     return flag ? fail(FHE_ERR_NONCANONICAL, "buffer holds coefficients that are not canonical residues of their limb modulus") : FHE_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------------------
+// relinearisation / key switching (general path: digit embedding -> batched forward NTT -> MAC -> inverse)
+// ------------------------------------------------------------------------------------------------------
+struct fhe_relin_keys {
+    fhe_rns_ntt *owner = nullptr;
+    uint32_t decomp_bits = 0, K = 0, num_keys = 0;
+    void *d_kb = nullptr, *d_ka = nullptr;      // [num_keys][L][n] containers, NTT domain, canonical
+};
+
+static uint32_t relin_digits(const fhe_rns_ntt *h, uint32_t w) {
+    int mx = 0;
+    for (const U256 &q : h->moduli) mx = q.bit_length() > mx ? q.bit_length() : mx;
+    return ((uint32_t)mx + w - 1) / w;
+}
+extern "C" int fhe_relin_num_digits(const fhe_rns_ntt_t *h, uint32_t decomp_bits, uint32_t *digits) {
+    if (!h || !digits) return fail(FHE_ERR_INVALID_ARG, "null argument");
+    if (decomp_bits < 1 || decomp_bits > 64) return fail(FHE_ERR_INVALID_ARG, "decomp_bits must be in [1, 64]");
+    *digits = relin_digits(h, decomp_bits);
+    return FHE_OK;
+}
+extern "C" int fhe_relin_keys_destroy(fhe_relin_keys_t *rk) {
+    if (rk) { if (rk->d_kb) (void)hipFree(rk->d_kb); if (rk->d_ka) (void)hipFree(rk->d_ka); delete rk; }
+    return FHE_OK;
+}
+extern "C" int fhe_relin_keys_create(fhe_rns_ntt_t *h, fhe_relin_keys_t **out, uint32_t decomp_bits,
+                                     const void *const *d_keys_b, const void *const *d_keys_a, uint32_t num_keys) {
+    if (!h || !out || !d_keys_b || !d_keys_a) return fail(FHE_ERR_INVALID_ARG, "relin_keys_create: null argument");
+    *out = nullptr;
+    if (decomp_bits < 1 || decomp_bits > 64) return fail(FHE_ERR_INVALID_ARG, "decomp_bits must be in [1, 64]");
+    const uint32_t K = relin_digits(h, decomp_bits);
+    if (num_keys != h->L * K) {
+        char buf[128]; snprintf(buf, sizeof buf, "relin_keys_create: expected %u keys (L = %u limbs x K = %u digits), got %u", h->L * K, h->L, K, num_keys);
+        return fail(FHE_ERR_INVALID_ARG, buf);
+    }
+    for (uint32_t i = 0; i < num_keys; i++) if (!d_keys_b[i] || !d_keys_a[i]) return fail(FHE_ERR_INVALID_ARG, "relin_keys_create: null key pointer");
+    (void)hipGetLastError();
+    fhe_relin_keys *rk = new (std::nothrow) fhe_relin_keys();
+    if (!rk) return fail(FHE_ERR_INVALID_ARG, "out of host memory");
+    rk->owner = h; rk->decomp_bits = decomp_bits; rk->K = K; rk->num_keys = num_keys;
+    const size_t S = (size_t)h->L * h->n * 32;
+    hipError_t e;
+    if ((e = hipMalloc(&rk->d_kb, S * num_keys)) != hipSuccess || (e = hipMalloc(&rk->d_ka, S * num_keys)) != hipSuccess) {
+        fhe_relin_keys_destroy(rk); return fail(FHE_ERR_HIP, std::string("relin_keys_create: ") + hipGetErrorString(e));
+    }
+    for (uint32_t i = 0; i < num_keys; i++) {
+        if ((e = hipMemcpyAsync((char *)rk->d_kb + i * S, d_keys_b[i], S, hipMemcpyDeviceToDevice, h->stream)) != hipSuccess ||
+            (e = hipMemcpyAsync((char *)rk->d_ka + i * S, d_keys_a[i], S, hipMemcpyDeviceToDevice, h->stream)) != hipSuccess) {
+            fhe_relin_keys_destroy(rk); return fail(FHE_ERR_HIP, std::string("relin_keys_create copy: ") + hipGetErrorString(e));
+        }
+    }
+    int rc = do_forward(h, rk->d_kb, num_keys);
+    if (!rc) rc = do_forward(h, rk->d_ka, num_keys);
+    if (rc) { fhe_relin_keys_destroy(rk); return rc; }
+    *out = rk;
+    return FHE_OK;
+}
+
+template <class F>
+static int relin_embed_mac_lds(fhe_rns_ntt *h, const fhe_relin_keys *rk, char *D, char *acc0, char *acc1, const void *c2, uint32_t chunk, int phase) {
+    using V = typename F::V16;
+    const uint32_t LK = h->L * rk->K;
+    if (phase == 0) {
+        size_t total = (size_t)LK * chunk * h->L * h->n * 2;
+        hipLaunchKernelGGL((fhe_dev::digit_embed_kernel<F>), dim3(ew_grid(total)), dim3(256), 0, h->stream, (V *)D, (const V *)c2,
+                           (const fhe_dev::Limb<F> *)h->d_limbs, h->L, h->log_n, rk->K, rk->decomp_bits, chunk);
+        return post_launch(h->stream, "digit_embed_kernel");
+    }
+    size_t halves = (size_t)chunk * h->L * h->n * 2;
+    hipLaunchKernelGGL((fhe_dev::relin_mac_kernel<F>), dim3(ew_grid(halves)), dim3(256), 0, h->stream, (V *)acc0, (V *)acc1, (const V *)D,
+                       (const V *)rk->d_kb, (const V *)rk->d_ka, (const fhe_dev::Limb<F> *)h->d_limbs, h->L, h->log_n, LK, chunk);
+    return post_launch(h->stream, "relin_mac_kernel");
+}
+static int relin_embed_mac(fhe_rns_ntt *h, const fhe_relin_keys *rk, char *D, char *acc0, char *acc1, const void *c2, uint32_t chunk, int phase) {
+    if (h->width == FHE_WIDTH_32) return relin_embed_mac_lds<fhe_dev::F32>(h, rk, D, acc0, acc1, c2, chunk, phase);
+    if (h->width == FHE_WIDTH_52) return relin_embed_mac_lds<fhe_dev::F52>(h, rk, D, acc0, acc1, c2, chunk, phase);
+    if (h->width == FHE_WIDTH_64) return relin_embed_mac_lds<fhe_dev::F64>(h, rk, D, acc0, acc1, c2, chunk, phase);
+    const uint32_t LK = h->L * rk->K;
+    if (phase == 0) {
+        size_t total = (size_t)LK * chunk * h->L * h->n;
+        hipLaunchKernelGGL(fhe_dev::digit_embed256_kernel, dim3(ew_grid(total)), dim3(256), 0, h->stream, (fhe_dev::u256 *)D, (const fhe_dev::u256 *)c2,
+                           (const fhe_dev::Limb256 *)h->d_limbs, h->L, h->log_n, rk->K, rk->decomp_bits, chunk);
+        return post_launch(h->stream, "digit_embed256_kernel");
+    }
+    size_t count = (size_t)chunk * h->L * h->n;
+    hipLaunchKernelGGL(fhe_dev::relin_mac256_kernel, dim3(ew_grid(count)), dim3(256), 0, h->stream, (fhe_dev::u256 *)acc0, (fhe_dev::u256 *)acc1,
+                       (const fhe_dev::u256 *)D, (const fhe_dev::u256 *)rk->d_kb, (const fhe_dev::u256 *)rk->d_ka,
+                       (const fhe_dev::Limb256 *)h->d_limbs, h->L, h->log_n, LK, chunk);
+    return post_launch(h->stream, "relin_mac256_kernel");
+}
+
+extern "C" int fhe_ct_relinearize(fhe_rns_ntt_t *h, const fhe_relin_keys_t *rk, void *d_c0, void *d_c1, const void *d_c2, uint32_t batch) {
+    int rc = check_call(h, batch, "ct_relinearize"); if (rc) return rc;
+    if (!rk || !d_c0 || !d_c1 || !d_c2) return fail(FHE_ERR_INVALID_ARG, "ct_relinearize: null argument");
+    if (rk->owner != h) return fail(FHE_ERR_INVALID_ARG, "ct_relinearize: keys were imported for a different engine");
+    if (d_c0 == d_c1 || d_c0 == d_c2 || d_c1 == d_c2) return fail(FHE_ERR_INVALID_ARG, "ct_relinearize: components must be distinct buffers");
+    const uint32_t LK = h->L * rk->K;
+    const size_t S = (size_t)h->L * h->n * 32;
+    // workspace: digit polynomials D[LK][chunk] + two accumulators; bounded to ~1 GiB, the batch is processed in chunks
+    uint32_t chunk = (uint32_t)(((size_t)1 << 30) / ((LK + 2) * S));
+    if (chunk < 1) chunk = 1;
+    if (chunk > batch) chunk = batch;
+    if ((rc = ensure_ws(h, (size_t)(LK + 2) * chunk * S))) return rc;
+    char *D = (char *)h->d_ws, *acc0 = D + (size_t)LK * chunk * S, *acc1 = acc0 + (size_t)chunk * S;
+    for (uint32_t done = 0; done < batch; done += chunk) {
+        const uint32_t nb = batch - done < chunk ? batch - done : chunk;
+        const char *c2 = (const char *)d_c2 + (size_t)done * S;
+        char *c0 = (char *)d_c0 + (size_t)done * S, *c1 = (char *)d_c1 + (size_t)done * S;
+        if ((rc = relin_embed_mac(h, rk, D, acc0, acc1, c2, nb, 0))) return rc;
+        if ((rc = do_forward(h, D, LK * nb))) return rc;
+        if ((rc = relin_embed_mac(h, rk, D, acc0, acc1, c2, nb, 1))) return rc;
+        if ((rc = do_inverse(h, acc0, nb))) return rc;
+        if ((rc = do_inverse(h, acc1, nb))) return rc;
+        if ((rc = do_ew<1>(h, c0, c0, acc0, nb, "relin add"))) return rc;
+        if ((rc = do_ew<1>(h, c1, c1, acc1, nb, "relin add"))) return rc;
+    }
+    return FHE_OK;
+}
+
 // ------------------------------------------------------------------------------------------------------
 // single-modulus engine ABI = RNS engine with one limb
 // ------------------------------------------------------------------------------------------------------

@@ -154,4 +154,50 @@ check256_kernel(const u256 *__restrict__ a, const Limb256 *__restrict__ limbs, u
     if (bad) atomicOr(flag, 1u);
 }
 
+// ---- relinearisation building blocks, full-width path (same layouts as the word-sized kernels) -----------------------
+__device__ __forceinline__ uint64_t extract_bits(const u256 &a, uint32_t lo, uint32_t w) {   // bits [lo, lo+w), w <= 64
+    if (lo >= 256) return 0;
+    const uint32_t limb = lo >> 6, sh = lo & 63;
+    uint64_t v = a.l[limb] >> sh;
+    if (sh && limb < 3) v |= a.l[limb + 1] << (64 - sh);
+    return w >= 64 ? v : (v & ((1ull << w) - 1));
+}
+__global__ void __launch_bounds__(256)
+digit_embed256_kernel(u256 *__restrict__ D, const u256 *__restrict__ c2, const Limb256 *__restrict__ limbs, uint32_t L,
+                      uint32_t log_n, uint32_t K, uint32_t w, uint32_t batch) {
+    const size_t per_poly = (size_t)1 << log_n, per_ct = per_poly * L, per_digit = per_ct * batch, total = per_digit * L * K;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += stride) {
+        const uint32_t jk = (uint32_t)(g / per_digit); const size_t rem = g - (size_t)jk * per_digit;
+        const uint32_t b = (uint32_t)(rem / per_ct); const size_t r2 = rem - (size_t)b * per_ct;
+        const uint32_t i = (uint32_t)(r2 >> log_n); const size_t x = r2 & (per_poly - 1);
+        const uint32_t j = jk / K, k = jk % K;
+        uint64_t d = extract_bits(load_u256(c2 + ((size_t)b * L + j) * per_poly + x), k * w, w);
+        const u256 q = limbs[i].q;
+        if (!(q.l[1] | q.l[2] | q.l[3])) d %= q.l[0];           // moduli above 2^64 exceed every digit
+        u256 o; o.l[0] = d; o.l[1] = o.l[2] = o.l[3] = 0;
+        store_u256(D + g, o);
+    }
+}
+__global__ void __launch_bounds__(256)
+relin_mac256_kernel(u256 *__restrict__ acc0, u256 *__restrict__ acc1, const u256 *__restrict__ D, const u256 *__restrict__ KB,
+                    const u256 *__restrict__ KA, const Limb256 *__restrict__ limbs, uint32_t L, uint32_t log_n, uint32_t LK,
+                    uint32_t batch) {
+    const size_t per_poly = (size_t)1 << log_n, per_ct = per_poly * L, per_digit = per_ct * batch;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < per_digit; g += stride) {
+        const size_t kidx = g % per_ct;
+        const Limb256 &P = limbs[(uint32_t)(kidx >> log_n)];
+        u256 s0, s1;
+        s0.l[0] = s0.l[1] = s0.l[2] = s0.l[3] = 0; s1 = s0;
+        for (uint32_t jk = 0; jk < LK; jk++) {
+            const u256 d = mont_mul(load_u256(D + (size_t)jk * per_digit + g), P.r2, P.q, P.inv0);      // d * R
+            s0 = add_mod(s0, mont_mul(d, load_u256(KB + (size_t)jk * per_ct + kidx), P.q, P.inv0), P.q);
+            s1 = add_mod(s1, mont_mul(d, load_u256(KA + (size_t)jk * per_ct + kidx), P.q, P.inv0), P.q);
+        }
+        store_u256(acc0 + g, s0);
+        store_u256(acc1 + g, s1);
+    }
+}
+
 }  // namespace fhe_dev

@@ -78,6 +78,7 @@ struct IntField {
     __device__ static __forceinline__ E ew_add(E x, E y, E q) { return csub<E>(x + y, q); }
     __device__ static __forceinline__ E ew_sub(E x, E y, E q) { return csub<E>(x - y + q, q); }
     __device__ static __forceinline__ bool ge(uint64_t raw, E q) { return raw >= (uint64_t)q; }
+    __device__ static __forceinline__ E from_u64(uint64_t d, E q) { return (E)(d % (uint64_t)q); }   // canonical residue of a small integer
 };
 
 struct F32 : IntField<F32, uint32_t, uint2> {
@@ -180,6 +181,7 @@ struct F52 {
     __device__ static __forceinline__ bool upper_nonzero(const V16 &v) { return v.y != 0; }
     __device__ static __forceinline__ bool any_nonzero(const V16 &v) { return (v.x | v.y) != 0; }
     __device__ static __forceinline__ bool ge(uint64_t raw, E q) { return (E)raw >= q; }
+    __device__ static __forceinline__ E from_u64(uint64_t d, E q) { return (E)(d % (uint64_t)q); }
 };
 
 // Per-limb constants (device memory, one entry per RNS prime).  *_s = Shoup companion floor(x*2^W/q).
@@ -620,6 +622,57 @@ check_kernel(const typename F::V16 *__restrict__ a, const Limb<F> *__restrict__ 
         else bad |= F::upper_nonzero(v) || F::ge(F::low(v), limbs[(uint32_t)((g >> (log_n + 1)) % L)].q);
     }
     if (bad) atomicOr(flag, 1u);
+}
+
+// ---- relinearisation building blocks (general path; the fused key-switch kernel for F32 is below) --------------------
+// Digit polynomials of c2 embedded in every limb: D[jk][b][i][x] = ((c2[b][j][x] >> (k*w)) & (2^w - 1)) mod q_i,
+// jk = j*K + k.  One 16-byte half container per lane.
+template <class F>
+__global__ void __launch_bounds__(256)
+digit_embed_kernel(typename F::V16 *__restrict__ D, const typename F::V16 *__restrict__ c2, const Limb<F> *__restrict__ limbs,
+                   uint32_t L, uint32_t log_n, uint32_t K, uint32_t w, uint32_t batch) {
+    using E = typename F::E;
+    const size_t per_poly = (size_t)2 << log_n, per_ct = per_poly * L, per_digit = per_ct * batch, total = per_digit * L * K;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += stride) {
+        E o = 0;
+        if (!(g & 1)) {
+            const uint32_t jk = (uint32_t)(g / per_digit); const size_t rem = g - (size_t)jk * per_digit;
+            const uint32_t b = (uint32_t)(rem / per_ct); const size_t r2 = rem - (size_t)b * per_ct;
+            const uint32_t i = (uint32_t)(r2 >> (log_n + 1)); const size_t x2 = r2 & (per_poly - 1);
+            const uint32_t j = jk / K, k = jk % K;
+            const uint64_t v = F::low(c2[((size_t)b * L + j) * per_poly + x2]);
+            const uint32_t sh = k * w;
+            uint64_t d = sh >= 64 ? 0 : (v >> sh);
+            if (w < 64) d &= (1ull << w) - 1;
+            o = F::from_u64(d, limbs[i].q);
+        }
+        __builtin_nontemporal_store(F::pack(o), D + g);
+    }
+}
+// acc0[b][i][x] = sum_jk D[jk][b][i][x] * KB[jk][i][x],  acc1 likewise with KA  (all NTT-domain, canonical)
+template <class F>
+__global__ void __launch_bounds__(256)
+relin_mac_kernel(typename F::V16 *__restrict__ acc0, typename F::V16 *__restrict__ acc1, const typename F::V16 *__restrict__ D,
+                 const typename F::V16 *__restrict__ KB, const typename F::V16 *__restrict__ KA, const Limb<F> *__restrict__ limbs,
+                 uint32_t L, uint32_t log_n, uint32_t LK, uint32_t batch) {
+    using E = typename F::E;
+    const size_t per_poly = (size_t)2 << log_n, per_ct = per_poly * L, per_digit = per_ct * batch;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < per_digit; g += stride) {
+        E s0 = 0, s1 = 0;
+        if (!(g & 1)) {
+            const size_t kidx = g % per_ct;
+            const Limb<F> &P = limbs[(uint32_t)(kidx >> (log_n + 1))];
+            for (uint32_t jk = 0; jk < LK; jk++) {
+                const E d = F::load_low(D + (size_t)jk * per_digit + g);
+                s0 = F::ew_add(s0, F::ew_mul(d, F::load_low(KB + (size_t)jk * per_ct + kidx), P), P.q);
+                s1 = F::ew_add(s1, F::ew_mul(d, F::load_low(KA + (size_t)jk * per_ct + kidx), P), P.q);
+            }
+        }
+        __builtin_nontemporal_store(F::pack(s0), acc0 + g);
+        __builtin_nontemporal_store(F::pack(s1), acc1 + g);
+    }
 }
 
 }  // namespace fhe_dev

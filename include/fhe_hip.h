@@ -137,6 +137,24 @@ int fhe_rns_poly_sub(fhe_rns_ntt_t *h, void *d_r, const void *d_a, const void *d
  * reference's 8 + 4 (results identical: modular arithmetic is exact). */
 int fhe_ct_multiply(fhe_rns_ntt_t *h, void *d_c0, void *d_c1, void *d_c2,
                     const void *d_a0, const void *d_a1, const void *d_b0, const void *d_b1, uint32_t batch);
+/* ---- relinearisation / key switching ------------------------------------------ */
+/* RelinKeys (include/fhe.cuh:52-55) as produced by FHEContext::relinkey_gen (src/fhe.cu:76-111):
+ * key pairs (b, a) with b = -a*s + e + g*s^2, one per decomposition level.  In the RNS representation every residue
+ * polynomial c2 mod q_j is decomposed into K = ceil(bits(q_max) / decomp_bits) base-2^w digit polynomials, so there are
+ * L*K levels; level j*K + k carries g = 2^(k*w) in limb j and g = 0 in the other limbs.  For L = 1 this is the
+ * reference's decomposition of a single-modulus ciphertext. */
+typedef struct fhe_relin_keys fhe_relin_keys_t;
+int fhe_relin_num_digits(const fhe_rns_ntt_t *h, uint32_t decomp_bits, uint32_t *digits_per_limb);
+/* d_keys_b / d_keys_a: host arrays of num_keys (= L*K) device pointers to [L][n] polynomials in coefficient form.
+ * The keys are copied, transformed to the NTT domain once and kept inside the returned object. */
+int fhe_relin_keys_create(fhe_rns_ntt_t *h, fhe_relin_keys_t **out, uint32_t decomp_bits,
+                          const void *const *d_keys_b, const void *const *d_keys_a, uint32_t num_keys);
+int fhe_relin_keys_destroy(fhe_relin_keys_t *rk);
+/* FHEContext::relinearize (src/fhe.cu:226-235 is a stub that drops c2; algorithm: docs/ARCHITECTURE.md:319-326):
+ * c0 += sum_{j,k} D_{j,k} * b_{j,k},  c1 += sum_{j,k} D_{j,k} * a_{j,k}  with D_{j,k} the digit polynomials of c2.
+ * c0, c1 are [batch][L][n] and updated in place; c2 is read only. */
+int fhe_ct_relinearize(fhe_rns_ntt_t *h, const fhe_relin_keys_t *rk, void *d_c0, void *d_c1, const void *d_c2, uint32_t batch);
+
 /* Scan a [batch][L][n] buffer for coefficients that are not canonical (>= q_limb, or non-zero
  * upper limbs on the narrow paths).  Synchronises.  FHE_OK or FHE_ERR_NONCANONICAL. */
 int fhe_rns_check_canonical(fhe_rns_ntt_t *h, const void *d_data, uint32_t batch);

@@ -346,6 +346,28 @@ void orc_polymul_schoolbook(const orc_plan *p, orc_u256 *r, const orc_u256 *a, c
 }
 
 /* ------------------------------------------------------------------------------------------ */
+static int u256_bits(const orc_u256 *a) {
+    for (int i = 3; i >= 0; i--) if (a->limbs[i]) return 64 * i + 64 - __builtin_clzll(a->limbs[i]);
+    return 0;
+}
+uint32_t orc_relin_num_digits(orc_plan *const *plans, uint32_t L, uint32_t decomp_bits) {
+    int mx = 0;
+    for (uint32_t l = 0; l < L; l++) { int b = u256_bits(&plans[l]->q); if (b > mx) mx = b; }
+    return ((uint32_t)mx + decomp_bits - 1) / decomp_bits;
+}
+/* bits [lo, lo+w) of a, w <= 64 */
+static uint64_t u256_extract(const orc_u256 *a, uint32_t lo, uint32_t w) {
+    if (lo >= 256) return 0;
+    uint32_t limb = lo / 64, sh = lo % 64;
+    uint64_t v = a->limbs[limb] >> sh;
+    if (sh && limb + 1 < 4) v |= a->limbs[limb + 1] << (64 - sh);
+    return w >= 64 ? v : (v & ((1ull << w) - 1));
+}
+static void reduce_small(const orc_plan *p, orc_u256 *r, uint64_t d) {   /* d mod q for a 64-bit d */
+    orc_u256 x = u256_from(d), t;
+    if (p->q.limbs[1] | p->q.limbs[2] | p->q.limbs[3]) { *r = x; return; }
+    x.limbs[0] = d % p->q.limbs[0]; *r = x; (void)t;
+}
 int orc_max_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();
@@ -412,5 +434,45 @@ int orc_ct_multiply(orc_plan *const *plans, uint32_t L, orc_u256 *c0, orc_u256 *
         orc_polymul_ntt(p, c2 + off, a1 + off, b1 + off);              /* :217 */
         free(t1); free(t2);
     }
+    return threads;
+}
+
+int orc_relinearize(orc_plan *const *plans, uint32_t L, uint32_t decomp_bits, orc_u256 *c0, orc_u256 *c1, const orc_u256 *c2,
+                    const orc_u256 *const *keys_b, const orc_u256 *const *keys_a, uint32_t batch, int threads) {
+    if (decomp_bits < 1 || decomp_bits > 64) return -1;
+    threads = clamp_threads(threads);
+    const uint32_t K = orc_relin_num_digits(plans, L, decomp_bits), n = plans[0]->n;
+    /* keys in NTT form, once */
+    size_t polyb = (size_t)n * sizeof(orc_u256);
+    orc_u256 *kb = (orc_u256 *)malloc(polyb * L * L * K), *ka = (orc_u256 *)malloc(polyb * L * L * K);
+    for (uint32_t jk = 0; jk < L * K; jk++)
+        for (uint32_t i = 0; i < L; i++) {
+            orc_u256 *db = kb + ((size_t)jk * L + i) * n, *da = ka + ((size_t)jk * L + i) * n;
+            memcpy(db, keys_b[jk] + (size_t)i * n, polyb); memcpy(da, keys_a[jk] + (size_t)i * n, polyb);
+            orc_ntt_forward(plans[i], db); orc_ntt_forward(plans[i], da);
+        }
+    long total = (long)batch * L;
+    #pragma omp parallel for num_threads(threads) schedule(dynamic) if (threads > 1)
+    for (long u = 0; u < total; u++) {
+        const uint32_t b = (uint32_t)(u / L), i = (uint32_t)(u % L);
+        const orc_plan *p = plans[i];
+        orc_u256 *acc0 = (orc_u256 *)calloc(n, sizeof(orc_u256)), *acc1 = (orc_u256 *)calloc(n, sizeof(orc_u256));
+        orc_u256 *d = (orc_u256 *)malloc(polyb), *t = (orc_u256 *)malloc(polyb);
+        for (uint32_t j = 0; j < L; j++) {
+            const orc_u256 *src = c2 + ((size_t)b * L + j) * n;
+            for (uint32_t k = 0; k < K; k++) {
+                for (uint32_t x = 0; x < n; x++) reduce_small(p, &d[x], u256_extract(&src[x], k * decomp_bits, decomp_bits));
+                orc_ntt_forward(p, d);
+                const uint32_t jk = j * K + k;
+                orc_ntt_pointwise(p, t, d, kb + ((size_t)jk * L + i) * n); orc_batch_add(acc0, acc0, t, &p->q, n);
+                orc_ntt_pointwise(p, t, d, ka + ((size_t)jk * L + i) * n); orc_batch_add(acc1, acc1, t, &p->q, n);
+            }
+        }
+        orc_ntt_inverse(p, acc0); orc_ntt_inverse(p, acc1);
+        orc_u256 *o0 = c0 + ((size_t)b * L + i) * n, *o1 = c1 + ((size_t)b * L + i) * n;
+        orc_batch_add(o0, o0, acc0, &p->q, n); orc_batch_add(o1, o1, acc1, &p->q, n);
+        free(acc0); free(acc1); free(d); free(t);
+    }
+    free(kb); free(ka);
     return threads;
 }

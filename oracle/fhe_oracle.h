@@ -98,6 +98,18 @@ int orc_rns_polymul(orc_plan *const *plans, uint32_t L, orc_u256 *r, const orc_u
 int orc_ct_multiply(orc_plan *const *plans, uint32_t L, orc_u256 *c0, orc_u256 *c1, orc_u256 *c2,
                     const orc_u256 *a0, const orc_u256 *a1, const orc_u256 *b0, const orc_u256 *b1,
                     uint32_t batch, int threads);
+/* Relinearisation / key switching -- FHEContext::relinearize (src/fhe.cu:226-235 is a stub that drops c2) with
+ * the keys of FHEContext::relinkey_gen (src/fhe.cu:76-111: rlk[i] = (-a_i s + e_i + 2^(i w) s^2, a_i)) and the algorithm
+ * text of docs/ARCHITECTURE.md:319-326 ("decompose c2 in base 2^w, ct' += d_i * rlk[i]"), carried to the RNS
+ * representation: every residue polynomial c2 mod q_j is decomposed into K = ceil(bits(q_max)/w) base-2^w digit
+ * polynomials D_{j,k}; key (j,k) = rlk[j*K + k] carries 2^(k w) s^2 in limb j and 0 s^2 in the other limbs.
+ *   c0'[i] = c0[i] + sum_{j,k} D_{j,k} (*) b_{j,k}[i]      c1'[i] = c1[i] + sum_{j,k} D_{j,k} (*) a_{j,k}[i]    (mod q_i)
+ * c0, c1 are updated in place; keys_b / keys_a are arrays of L*K pointers to [L][n] polynomials (coefficient form).
+ * For L = 1 this is exactly the reference's single-modulus decomposition.  "parity unpinned": the reference holds no
+ * working implementation; tests pin it through Dec(relin(ct)) == Dec(ct) with Python big integers. */
+uint32_t orc_relin_num_digits(orc_plan *const *plans, uint32_t L, uint32_t decomp_bits);
+int orc_relinearize(orc_plan *const *plans, uint32_t L, uint32_t decomp_bits, orc_u256 *c0, orc_u256 *c1, const orc_u256 *c2,
+                    const orc_u256 *const *keys_b, const orc_u256 *const *keys_a, uint32_t batch, int threads);
 int orc_max_threads(void);
 
 #ifdef __cplusplus

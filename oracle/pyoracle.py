@@ -72,6 +72,8 @@ def lib():
             "orc_rns_polymul": (ci, [ctypes.POINTER(vp), u32, P, P, P, u32, ci]),
             "orc_ct_multiply": (ci, [ctypes.POINTER(vp), u32] + [P] * 7 + [u32, ci]),
             "orc_max_threads": (ci, []),
+            "orc_relin_num_digits": (u32, [ctypes.POINTER(vp), u32, u32]),
+            "orc_relinearize": (ci, [ctypes.POINTER(vp), u32, u32, P, P, P, ctypes.POINTER(P), ctypes.POINTER(P), u32, ci]),
         }
         for name, (res, args) in sig.items():
             fn = getattr(L, name)
@@ -266,6 +268,27 @@ class RnsPlan:
         lib().orc_ct_multiply(self._arr, self.L, _p(c0), _p(c1), _p(c2), _p(a0), _p(a1), _p(b0), _p(b1),
                               self._batch(a0), threads)
         return c0, c1, c2
+
+
+def _rns_relin(self, decomp_bits, c0, c1, c2, keys_b, keys_a, threads=1):
+    """c0', c1' (copies) after key switching c2 with the L*K keys (each a [L][n] limb array, coefficient form)."""
+    P = ctypes.POINTER(U256)
+    K = int(lib().orc_relin_num_digits(self._arr, self.L, decomp_bits))
+    assert len(keys_b) == len(keys_a) == self.L * K, (len(keys_b), self.L, K)
+    kb = [np.ascontiguousarray(k, dtype=np.uint64) for k in keys_b]; ka = [np.ascontiguousarray(k, dtype=np.uint64) for k in keys_a]
+    pb = (P * len(kb))(*[_p(k) for k in kb]); pa = (P * len(ka))(*[_p(k) for k in ka])
+    o0, o1 = c0.copy(), c1.copy()
+    rc = lib().orc_relinearize(self._arr, self.L, decomp_bits, _p(o0), _p(o1), _p(np.ascontiguousarray(c2)), pb, pa, self._batch(c2), threads)
+    assert rc > 0
+    return o0, o1
+
+
+def _rns_num_digits(self, decomp_bits):
+    return int(lib().orc_relin_num_digits(self._arr, self.L, decomp_bits))
+
+
+RnsPlan.relinearize = _rns_relin
+RnsPlan.num_digits = _rns_num_digits
 
 
 def max_threads():

@@ -311,3 +311,64 @@ def test_golden_digests_on_device(eng, oracle, golden_dir):
         fa = dA.download(a.shape)
         assert hashlib.sha256(fa.tobytes()).hexdigest() == c["forward_sha256"]
         assert [int(v) for v in fa[0, 0, :8, 0]] == c["forward_first8"]
+
+
+# ------------------------------------------------------------------------------------ N1: relinearisation
+def _random_keys(moduli, n, count, seed):
+    return [rns_poly(seed + 17 * i, moduli, n, 1)[0] for i in range(count)]
+
+
+@pytest.mark.parametrize("n,spec,w,batch", [(2048, [40961], 8, 2), (8192, ("bits", 30, 4), 16, 3), (4096, ("bits", 30, 2), 30, 2),
+                                            (4096, ("bits", 40, 3), 20, 2), (2048, ("bits", 60, 2), 32, 1), (256, ("bits", 250, 2), 64, 2),
+                                            (1024, [12289], 16, 2)])
+def test_relinearize_matches_oracle(eng, oracle, n, spec, w, batch):
+    """FHEContext::relinearize semantics (DESIGN.md, N1) on every width class, arbitrary key material."""
+    moduli = _moduli(spec, n); L = len(moduli)
+    e = eng.RnsNttEngine(n, moduli); rp = oracle.RnsPlan(n, moduli)
+    K = e.relin_num_digits(w)
+    assert K == rp.num_digits(w)
+    kb = _random_keys(moduli, n, L * K, 100); ka = _random_keys(moduli, n, L * K, 900)
+    c0, c1, c2 = (rns_poly(s, moduli, n, batch) for s in (51, 52, 53))
+    dkb = [_up(eng, k) for k in kb]; dka = [_up(eng, k) for k in ka]
+    rk = e.import_relin_keys(w, dkb, dka)
+    d0, d1, d2 = _up(eng, c0), _up(eng, c1), _up(eng, c2)
+    e.relinearize(rk, d0, d1, d2, batch)
+    w0, w1 = rp.relinearize(w, c0, c1, c2, kb, ka, threads=8)
+    assert np.array_equal(d0.download(c0.shape), w0)
+    assert np.array_equal(d1.download(c0.shape), w1)
+    assert np.array_equal(d2.download(c0.shape), c2)
+    with pytest.raises(eng.FheError):
+        e.import_relin_keys(w, dkb[:-1], dka[:-1])
+
+
+def test_reference_fhe_scenario_on_gpu(eng, oracle):
+    """tests/test_fhe.cu:169-273 at its own size (N = 4096, t = 65537) on the multiply path: encrypt on the host (toy BGV,
+    test code), tensor product + relinearisation on the GPU, decrypt on the host: 15 60 135 240 and 8 16 24 32."""
+    import bgv_toy
+    n, t, w = 4096, 65537, 16
+    moduli = eng.find_ntt_primes(30, n, 4)                      # log_q = 120
+    rp = oracle.RnsPlan(n, moduli)
+
+    def fast_mul(x, y):
+        return bgv_toy.from_limb_array(rp.polymul(bgv_toy.to_limb_array(x), bgv_toy.to_limb_array(y), threads=8))
+
+    S = bgv_toy.ToyBGV(n, moduli, t, seed=11, fast_mul=fast_mul)
+    m1 = S.slot_encode([5, 10, 15, 20]); m2 = S.slot_encode([3, 6, 9, 12])
+    a0, a1 = S.encrypt(m1); b0, b1 = S.encrypt(m2)
+    kb, ka, K = S.relin_keys(w)
+    e = eng.RnsNttEngine(n, moduli)
+    d = [_up(eng, bgv_toy.to_limb_array(x)) for x in (a0, a1, b0, b1)]
+    c = [eng.DeviceBuffer(d[0].nbytes) for _ in range(3)]
+    rk = e.import_relin_keys(w, [_up(eng, bgv_toy.to_limb_array(k)[0]) for k in kb], [_up(eng, bgv_toy.to_limb_array(k)[0]) for k in ka])
+    e.ct_multiply(c[0], c[1], c[2], d[0], d[1], d[2], d[3], 1)
+    shape = (1, 4, n, 4)
+    three = [bgv_toy.from_limb_array(x.download(shape)) for x in c]
+    assert S.slot_decode(S.decrypt(three))[:4] == [15, 60, 135, 240]
+    e.relinearize(rk, c[0], c[1], c[2], 1)
+    two = [bgv_toy.from_limb_array(x.download(shape)) for x in c[:2]]
+    got = S.slot_decode(S.decrypt(two))
+    assert got[:4] == [15, 60, 135, 240] and not any(got[4:])
+    s0, s1 = eng.DeviceBuffer(d[0].nbytes), eng.DeviceBuffer(d[0].nbytes)
+    e.poly_add(s0, d[0], d[2], 1); e.poly_add(s1, d[1], d[3], 1)
+    summed = [bgv_toy.from_limb_array(x.download(shape)) for x in (s0, s1)]
+    assert S.slot_decode(S.decrypt(summed))[:4] == [8, 16, 24, 32]

@@ -221,3 +221,48 @@ def test_plan_rejects_bad_moduli(oracle):
         oracle.Plan(1000, 12289)           # n not a power of two
     with pytest.raises(ValueError):
         oracle.Plan(8, (1 << 39) + 1)      # composite (3^2 * 2731 * 22366891): what src/rns.cu:199-204 returns
+
+
+# ---------------------------------------------------------------------------------- N1: relinearisation
+@pytest.mark.parametrize("n,bits,L,w,t", [(64, 30, 2, 16, 257), (64, 30, 3, 30, 257), (32, 60, 1, 16, 193), (32, 40, 2, 20, 193)])
+def test_relinearisation_decrypts_like_the_three_component_ciphertext(oracle, n, bits, L, w, t):
+    """Dec(relin(c0,c1,c2)) == Dec(c0,c1,c2) == m1*m2, with the toy BGV of tests/bgv_toy.py (big-int CRT)."""
+    import bgv_toy
+    moduli = nm.ntt_primes(bits, n, L)
+    S = bgv_toy.ToyBGV(n, moduli, t, seed=n + L)
+    rp = oracle.RnsPlan(n, moduli)
+    rng = random.Random(5)
+    m1 = [rng.randrange(t) for _ in range(n)]; m2 = [rng.randrange(t) for _ in range(n)]
+    a0, a1 = S.encrypt(m1); b0, b1 = S.encrypt(m2)
+    A0, A1, B0, B1 = (bgv_toy.to_limb_array(x) for x in (a0, a1, b0, b1))
+    c0, c1, c2 = rp.ct_multiply(A0, A1, B0, B1)
+    want = nm.negacyclic_mul_direct(m1, m2, t)
+    assert S.decrypt([bgv_toy.from_limb_array(c) for c in (c0, c1, c2)]) == want
+    kb, ka, K = S.relin_keys(w)
+    assert K == rp.num_digits(w)
+    KB = [bgv_toy.to_limb_array(k)[0] for k in kb]; KA = [bgv_toy.to_limb_array(k)[0] for k in ka]
+    r0, r1 = rp.relinearize(w, c0, c1, c2, KB, KA, threads=2)
+    assert S.decrypt([bgv_toy.from_limb_array(r0), bgv_toy.from_limb_array(r1)]) == want
+    assert not np.array_equal(r0, c0)
+
+
+def test_reference_fhe_expectation_15_60_135_240(oracle):
+    """tests/test_fhe.cu:169-273: {5,10,15,20} x {3,6,9,12} -> 15 60 135 240, and {..}+{..} -> 8 16 24 32, through
+    tensor product + relinearisation (the reference prints these expectations but cannot reach them)."""
+    import bgv_toy
+    n, t, w = 64, 257, 16
+    moduli = nm.ntt_primes(30, n, 2)
+    S = bgv_toy.ToyBGV(n, moduli, t, seed=3)
+    rp = oracle.RnsPlan(n, moduli)
+    m1 = S.slot_encode([5, 10, 15, 20]); m2 = S.slot_encode([3, 6, 9, 12])
+    a0, a1 = S.encrypt(m1); b0, b1 = S.encrypt(m2)
+    A0, A1, B0, B1 = (bgv_toy.to_limb_array(x) for x in (a0, a1, b0, b1))
+    c0, c1, c2 = rp.ct_multiply(A0, A1, B0, B1)
+    kb, ka, K = S.relin_keys(w)
+    r0, r1 = rp.relinearize(w, c0, c1, c2, [bgv_toy.to_limb_array(k)[0] for k in kb], [bgv_toy.to_limb_array(k)[0] for k in ka])
+    got = S.slot_decode(S.decrypt([bgv_toy.from_limb_array(r0), bgv_toy.from_limb_array(r1)]))
+    assert got[:4] == [15, 60, 135, 240] and not any(got[4:])
+    s0 = oracle.batch_add(np.ascontiguousarray(A0[0, 0]), np.ascontiguousarray(B0[0, 0]), moduli[0])
+    sum_ct = [S.add(a0, b0), S.add(a1, b1)]
+    assert S.slot_decode(S.decrypt(sum_ct))[:4] == [8, 16, 24, 32]
+    assert [int(v) for v in s0[:, 0]] == sum_ct[0][0]
