@@ -40,9 +40,11 @@ def parse():
     ap.add_argument("--limbs", type=int, default=4)
     ap.add_argument("--bits", type=int, default=30, help="bit length of each RNS prime (30 = log_q 120 / 4 limbs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--op", choices=["multiply", "fwdinv", "ct"], default="multiply",
+    ap.add_argument("--op", choices=["multiply", "fwdinv", "ct", "relin", "ctrelin"], default="multiply",
                     help="multiply = fused polymul (the headline, configs[1]); fwdinv = forward+inverse NTT pair; "
-                         "ct = ciphertext tensor product (configs[2]/[3] without relinearisation)")
+                         "ct = ciphertext tensor product; relin = key switching of c2 into (c0, c1); "
+                         "ctrelin = tensor product + relinearisation (configs[2]: full ciphertext multiply)")
+    ap.add_argument("--decomp-bits", type=int, default=16, help="relinearisation digit width w (reference default 16)")
     ap.add_argument("--extras", action="store_true", help="also time forward+inverse pairs")
     return ap.parse_args()
 
@@ -121,7 +123,7 @@ def main():
     moduli = pkg.find_ntt_primes(args.bits, n, L)
     eng = pkg.RnsNttEngine(n, moduli)
     S = 32 * n * L                                   # bytes of one RNS polynomial
-    n_in, n_out = {"multiply": (2, 1), "fwdinv": (1, 0), "ct": (4, 3)}[args.op]
+    n_in, n_out = {"multiply": (2, 1), "fwdinv": (1, 0), "ct": (4, 3), "relin": (3, 0), "ctrelin": (4, 3)}[args.op]
     ins = [pkg.DeviceBuffer(B * S) for _ in range(n_in)]
     outs = [pkg.DeviceBuffer(B * S) for _ in range(n_out)]
     for i, buf in enumerate(ins):
@@ -138,10 +140,26 @@ def main():
         step = lambda: (eng.forward(dA, B), eng.inverse(dA, B))
         unit, units_per_poly_bytes, kernel = "ntt-pair/s", 4, "ntt_forward_kernel+ntt_inverse_kernel"
         what = "batched forward + inverse NTT pair (in place)"
-    else:
+    elif args.op == "ct":
         step = lambda: eng.ct_multiply(outs[0], outs[1], outs[2], ins[0], ins[1], ins[2], ins[3], B)
         unit, units_per_poly_bytes, kernel = "ct-mul/s", 7, "ntt_ct_multiply_kernel"
         what = "ciphertext tensor product c0=a0b0, c1=a0b1+a1b0, c2=a1b1 (no relinearisation)"
+    else:
+        from workload import rns_poly
+        K = eng.relin_num_digits(args.decomp_bits)
+        keys = [[pkg.DeviceBuffer.from_numpy(rns_poly(7000 + 31 * i + 997 * h, moduli, n, 1)) for i in range(L * K)] for h in range(2)]
+        rk = eng.import_relin_keys(args.decomp_bits, keys[0], keys[1])
+        if args.op == "relin":
+            step = lambda: eng.relinearize(rk, ins[0], ins[1], ins[2], B)
+            # read c2 once (re-reads by the L limb workgroups are cache traffic), read + write c0 and c1
+            unit, units_per_poly_bytes, kernel = "relin/s", 5, "ntt_keyswitch_kernel"
+            what = f"relinearisation: key switching of c2 into (c0, c1), w = {args.decomp_bits}, {L * K} key levels"
+        else:
+            def step():
+                eng.ct_multiply(outs[0], outs[1], outs[2], ins[0], ins[1], ins[2], ins[3], B)
+                eng.relinearize(rk, outs[0], outs[1], outs[2], B)
+            unit, units_per_poly_bytes, kernel = "ct-mul/s", 12, "ntt_ct_multiply_kernel+ntt_keyswitch_kernel"
+            what = f"full ciphertext multiply: tensor product (7*S) + relinearisation (5*S), w = {args.decomp_bits}"
 
     def barrier():
         pkg.capi.sync()
@@ -171,7 +189,7 @@ def main():
     ms_per_step = wall * 1e3 / args.steps
     value = B * world / (wall / args.steps)
     launch_ms = ev_ms / args.steps                   # HIP-event time of one step's launches on the engine stream
-    algo_bytes = units_per_poly_bytes * S * B        # 3*S per polymul, 4*S per fwd+inv pair, 7*S per ct-mul
+    algo_bytes = units_per_poly_bytes * S * B        # 3*S per polymul, 4*S per fwd+inv pair, 7*S per ct-mul (+5*S relin)
     achieved = algo_bytes / (launch_ms * 1e-3) / 1e9
     width = {1: "u32", 2: "u64", 3: "f64 (exact integers < 2^53)", 4: "u256"}[eng.width_class]
     metric = "NTT-polymul/sec (N=8192, 4 RNS limbs) + achieved HBM GB/s vs peak"

@@ -587,6 +587,7 @@ struct fhe_relin_keys {
     fhe_rns_ntt *owner = nullptr;
     uint32_t decomp_bits = 0, K = 0, num_keys = 0;
     void *d_kb = nullptr, *d_ka = nullptr;      // [num_keys][L][n] containers, NTT domain, canonical
+    void *d_pkb = nullptr, *d_pka = nullptr;    // packed tables for the fused key-switch kernel (32-bit path only)
 };
 
 static uint32_t relin_digits(const fhe_rns_ntt *h, uint32_t w) {
@@ -601,7 +602,10 @@ extern "C" int fhe_relin_num_digits(const fhe_rns_ntt_t *h, uint32_t decomp_bits
     return FHE_OK;
 }
 extern "C" int fhe_relin_keys_destroy(fhe_relin_keys_t *rk) {
-    if (rk) { if (rk->d_kb) (void)hipFree(rk->d_kb); if (rk->d_ka) (void)hipFree(rk->d_ka); delete rk; }
+    if (rk) {
+        for (void *p : {rk->d_kb, rk->d_ka, rk->d_pkb, rk->d_pka}) if (p) (void)hipFree(p);
+        delete rk;
+    }
     return FHE_OK;
 }
 extern "C" int fhe_relin_keys_create(fhe_rns_ntt_t *h, fhe_relin_keys_t **out, uint32_t decomp_bits,
@@ -632,6 +636,18 @@ extern "C" int fhe_relin_keys_create(fhe_rns_ntt_t *h, fhe_relin_keys_t **out, u
     }
     int rc = do_forward(h, rk->d_kb, num_keys);
     if (!rc) rc = do_forward(h, rk->d_ka, num_keys);
+    if (!rc && h->width == FHE_WIDTH_32 && !getenv("FHE_HIP_NO_FUSED_KEYSWITCH")) {
+        using F = fhe_dev::F32;
+        const size_t elems = (size_t)num_keys * h->L * h->n;
+        if ((e = hipMalloc(&rk->d_pkb, elems * sizeof(F::E))) != hipSuccess || (e = hipMalloc(&rk->d_pka, elems * sizeof(F::E))) != hipSuccess) {
+            fhe_relin_keys_destroy(rk); return fail(FHE_ERR_HIP, std::string("relin_keys_create: ") + hipGetErrorString(e));
+        }
+        hipLaunchKernelGGL((fhe_dev::pack_keys_kernel<F>), dim3(ew_grid(elems)), dim3(256), 0, h->stream, (F::E *)rk->d_pkb, (const F::V16 *)rk->d_kb,
+                           (const fhe_dev::Limb<F> *)h->d_limbs, h->L, h->log_n, num_keys);
+        hipLaunchKernelGGL((fhe_dev::pack_keys_kernel<F>), dim3(ew_grid(elems)), dim3(256), 0, h->stream, (F::E *)rk->d_pka, (const F::V16 *)rk->d_ka,
+                           (const fhe_dev::Limb<F> *)h->d_limbs, h->L, h->log_n, num_keys);
+        rc = post_launch(h->stream, "pack_keys_kernel");
+    }
     if (rc) { fhe_relin_keys_destroy(rk); return rc; }
     *out = rk;
     return FHE_OK;
@@ -675,6 +691,14 @@ extern "C" int fhe_ct_relinearize(fhe_rns_ntt_t *h, const fhe_relin_keys_t *rk, 
     if (!rk || !d_c0 || !d_c1 || !d_c2) return fail(FHE_ERR_INVALID_ARG, "ct_relinearize: null argument");
     if (rk->owner != h) return fail(FHE_ERR_INVALID_ARG, "ct_relinearize: keys were imported for a different engine");
     if (d_c0 == d_c1 || d_c0 == d_c2 || d_c1 == d_c2) return fail(FHE_ERR_INVALID_ARG, "ct_relinearize: components must be distinct buffers");
+    if (rk->d_pkb) {   // 32-bit path: one fused launch
+        fhe_dev::lds_launch_fn fn = fhe_dev::lds_lookup(32, (int)h->log_n);
+        if (!fn) return fail(FHE_ERR_UNSUPPORTED, "transform size outside the LDS-resident range");
+        fhe_dev::LdsArgs A{fhe_dev::LDS_KEYSWITCH, d_c0, d_c1, nullptr, d_c2, nullptr, nullptr, nullptr, h->d_limbs, h->L, batch * h->L, h->stream};
+        A.kb = rk->d_pkb; A.ka = rk->d_pka; A.K = rk->K; A.w = rk->decomp_bits;
+        fn(A);
+        return post_launch(h->stream, "ntt_keyswitch_kernel");
+    }
     const uint32_t LK = h->L * rk->K;
     const size_t S = (size_t)h->L * h->n * 32;
     // workspace: digit polynomials D[LK][chunk] + two accumulators; bounded to ~1 GiB, the batch is processed in chunks

@@ -39,6 +39,12 @@ void CAT(lds_launch_, FHE_FIELD, FHE_LOGN)(const LdsArgs &A) {
                                    (const char *)A.b1, (const char *)A.a1, (const char *)A.b0, limbs, A.L);
             }
             break;
+        case LDS_KEYSWITCH:
+            if constexpr (lds_keyswitch_fused(sizeof(typename F::E))) {
+                hipLaunchKernelGGL((ntt_keyswitch_kernel<F, LOGN, 2>), grid, block, 0, A.stream, (char *)A.r0, (char *)A.r1, (const char *)A.a0,
+                                   (const typename F::E *)A.kb, (const typename F::E *)A.ka, limbs, A.L, A.K, A.w);
+            }
+            break;
     }
 }
 

@@ -6,11 +6,13 @@
 
 namespace fhe_dev {
 
-enum LdsOp { LDS_FORWARD = 0, LDS_INVERSE = 1, LDS_MULTIPLY = 2, LDS_CT_MULTIPLY = 3 };
+enum LdsOp { LDS_FORWARD = 0, LDS_INVERSE = 1, LDS_MULTIPLY = 2, LDS_CT_MULTIPLY = 3, LDS_KEYSWITCH = 4 };
 
 // true when the instance runs the tensor product as one fused launch; otherwise LDS_CT_MULTIPLY issues
 // multiply(c0), multiply(c2) and the two-product kernel for c1 (three launches, 11*S instead of 7*S bytes)
 constexpr bool lds_ct_fused(int elem_bytes, int log_n) { return elem_bytes == 4 || log_n <= 13; }
+// the fused key-switch kernel keeps four 32-element arrays per thread: instantiated for 4-byte residues only
+constexpr bool lds_keyswitch_fused(int elem_bytes) { return elem_bytes == 4; }
 
 struct LdsArgs {
     int op;
@@ -19,6 +21,8 @@ struct LdsArgs {
     const void *limbs;                   // device array of Limb<F>
     uint32_t L, polys;
     hipStream_t stream;
+    const void *kb = nullptr, *ka = nullptr;   // LDS_KEYSWITCH: packed key tables (r0 = c0, r1 = c1, a0 = c2)
+    uint32_t K = 0, w = 0;
 };
 
 typedef void (*lds_launch_fn)(const LdsArgs &);

@@ -79,6 +79,13 @@ struct IntField {
     __device__ static __forceinline__ E ew_sub(E x, E y, E q) { return csub<E>(x - y + q, q); }
     __device__ static __forceinline__ bool ge(uint64_t raw, E q) { return raw >= (uint64_t)q; }
     __device__ static __forceinline__ E from_u64(uint64_t d, E q) { return (E)(d % (uint64_t)q); }   // canonical residue of a small integer
+    // bits [lo, lo+w) of a residue (lo < bit width of E)
+    __device__ static __forceinline__ E digit(E x, uint32_t lo, uint32_t w) {
+        E v = x >> lo;
+        return w >= 8 * sizeof(E) ? v : (E)(v & (((E)1 << w) - 1));
+    }
+    // canonical x -> the operand form pw_mul expects on its canonical side so that the product comes out plain: x * 2^W mod q
+    template <class L> __device__ static __forceinline__ E to_pw_operand(E x, const L &P) { return csub<E>(Self::shoup_mul(x, P.r1, P.r1_s, P.q), P.q); }
 };
 
 struct F32 : IntField<F32, uint32_t, uint2> {
@@ -182,6 +189,11 @@ struct F52 {
     __device__ static __forceinline__ bool any_nonzero(const V16 &v) { return (v.x | v.y) != 0; }
     __device__ static __forceinline__ bool ge(uint64_t raw, E q) { return (E)raw >= q; }
     __device__ static __forceinline__ E from_u64(uint64_t d, E q) { return (E)(d % (uint64_t)q); }
+    __device__ static __forceinline__ E digit(E x, uint32_t lo, uint32_t w) {
+        uint64_t v = (uint64_t)x >> lo;
+        return (E)(w >= 64 ? v : (v & ((1ull << w) - 1)));
+    }
+    template <class L> __device__ static __forceinline__ E to_pw_operand(E x, const L &) { return x; }
 };
 
 // Per-limb constants (device memory, one entry per RNS prime).  *_s = Shoup companion floor(x*2^W/q).
@@ -622,6 +634,95 @@ check_kernel(const typename F::V16 *__restrict__ a, const Limb<F> *__restrict__ 
         else bad |= F::upper_nonzero(v) || F::ge(F::low(v), limbs[(uint32_t)((g >> (log_n + 1)) % L)].q);
     }
     if (bad) atomicOr(flag, 1u);
+}
+
+// ---- fused key switching (relinearisation) -----------------------------------------------------------------------------
+// Key tables in the kernel's own register order ("packed"): for level jk and limb i, element (chunk c, thread tid, e) holds
+// KEY_ntt[i][tid*32 + c*VPL + e] * 2^W mod q_i, VPL = 16 / sizeof(E) values per 16-byte lane load, so a wave instruction
+// reads 1 KiB contiguous and pw_mul's 2^-W cancels.  Tables for one engine total 2 * L*K * L * N * sizeof(E) bytes
+// (2 MiB at N = 8192, L = 4, K = 2, F32) and stay L2-resident across the batch.
+template <class F>
+__global__ void __launch_bounds__(256)
+pack_keys_kernel(typename F::E *__restrict__ packed, const typename F::V16 *__restrict__ keys_ntt, const Limb<F> *__restrict__ limbs,
+                 uint32_t L, uint32_t log_n, uint32_t num_keys) {
+    using E = typename F::E;
+    constexpr uint32_t VPL = 16 / sizeof(E);
+    const uint32_t n = 1u << log_n, T = n >> 5;
+    const size_t total = (size_t)num_keys * L * n, stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += stride) {
+        const uint32_t x = (uint32_t)(g & (n - 1));                  // NTT-domain index = tid*32 + r
+        const size_t poly = g >> log_n;                              // jk * L + i
+        const Limb<F> &P = limbs[(uint32_t)(poly % L)];
+        const uint32_t tid = x >> 5, r = x & 31, c = r / VPL, e = r % VPL;
+        E v = F::load_low(keys_ntt + g * 2);
+        packed[poly * n + ((size_t)c * T + tid) * VPL + e] = F::to_pw_operand(v, P);
+    }
+}
+
+// One workgroup per (ciphertext b, limb i): for every limb j of c2 and every digit k, the digit polynomial is formed in
+// registers, transformed under q_i, multiplied with both key halves and accumulated in the NTT domain; two inverse
+// transforms and the additions to c0, c1 finish the job.  HBM traffic per ciphertext: L reads of c2 + read/write of c0, c1
+// = (L + 4) * S bytes (re-reads of c2 by the L workgroups of one ciphertext mostly hit the Infinity Cache).
+template <class F, int LOGN, int MINW = 1>
+__global__ void __launch_bounds__(NttCfg<LOGN>::T, MINW)
+ntt_keyswitch_kernel(char *__restrict__ c0, char *__restrict__ c1, const char *__restrict__ c2,
+                     const typename F::E *__restrict__ kb, const typename F::E *__restrict__ ka,
+                     const Limb<F> *__restrict__ limbs, uint32_t L, uint32_t K, uint32_t w) {
+    using C = NttCfg<LOGN>;
+    using E = typename F::E;
+    constexpr int VPL = 16 / sizeof(E), NCH = 32 / VPL;
+    typedef E VecE __attribute__((ext_vector_type(VPL)));
+    __shared__ E lds[C::LDS_ELEMS];
+    // XCD-aware workgroup -> (ciphertext, limb) map: workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8
+    // names the L2 a workgroup shares), and the L limb-workgroups of one ciphertext all re-read the same c2, so they are
+    // given block indices that are congruent mod 8 and at most 8*L apart: the re-reads then hit one XCD's L2 instead of
+    // crossing the fabric L times.  Placement only changes speed, never results.
+    const uint32_t tid = threadIdx.x, bid = blockIdx.x, full = (gridDim.x / (8 * L)) * (8 * L);
+    uint32_t b, i;
+    if (bid < full) { const uint32_t s = bid >> 3; b = (bid & 7) + 8 * (s / L); i = s % L; }
+    else { b = bid / L; i = bid % L; }
+    const uint32_t p = b * L + i;
+    const Limb<F> P = limbs[i];
+    E acc0[32], acc1[32], x[32], d[32];
+#pragma unroll
+    for (int r = 0; r < 32; r++) { acc0[r] = 0; acc1[r] = 0; }
+    for (uint32_t j = 0; j < L; j++) {
+        load_A<F, LOGN>(c2 + ((size_t)b * L + j) * (C::N * 32), tid, x);
+        for (uint32_t k = 0; k < K; k++) {
+#pragma unroll
+            for (int r = 0; r < 32; r++) d[r] = F::digit(x[r], k * w, w);
+            fwd_core<F, LOGN>(d, lds, tid, P);
+            const size_t tbl = ((size_t)(j * K + k) * L + i) * C::N;
+            const VecE *pb = reinterpret_cast<const VecE *>(kb + tbl) + tid, *pa = reinterpret_cast<const VecE *>(ka + tbl) + tid;
+#pragma unroll
+            for (int c = 0; c < NCH; c++) {
+                const VecE vb = pb[c * C::T], va = pa[c * C::T];
+#pragma unroll
+                for (int e = 0; e < VPL; e++) {
+                    const int r = c * VPL + e;
+                    acc0[r] = F::pw_add(acc0[r], F::pw_mul(vb[e], d[r], P.q, P.qinv), P.q, P.q2);
+                    acc1[r] = F::pw_add(acc1[r], F::pw_mul(va[e], d[r], P.q, P.qinv), P.q, P.q2);
+                }
+            }
+            __syncthreads();                      // every Z-pattern read is done before the next digit's exchange
+        }
+    }
+    // acc0 -> coefficient domain, + c0
+    inv_core<F, LOGN>(acc0, lds, tid, P, P.ninv, P.ninv_s, P.ninvw, P.ninvw_s);
+    load_A<F, LOGN>(c0 + (size_t)p * (C::N * 32), tid, x);
+#pragma unroll
+    for (int r = 0; r < 32; r++) acc0[r] = F::ew_add(F::canon_inv(acc0[r], P.q), x[r], P.q);
+    lds_put<PatA<LOGN>>(lds, tid, acc0);
+    __syncthreads();
+    store_from_lds<F, LOGN>(c0 + (size_t)p * (C::N * 32), lds, tid);
+    __syncthreads();
+    inv_core<F, LOGN>(acc1, lds, tid, P, P.ninv, P.ninv_s, P.ninvw, P.ninvw_s);
+    load_A<F, LOGN>(c1 + (size_t)p * (C::N * 32), tid, x);
+#pragma unroll
+    for (int r = 0; r < 32; r++) acc1[r] = F::ew_add(F::canon_inv(acc1[r], P.q), x[r], P.q);
+    lds_put<PatA<LOGN>>(lds, tid, acc1);
+    __syncthreads();
+    store_from_lds<F, LOGN>(c1 + (size_t)p * (C::N * 32), lds, tid);
 }
 
 // ---- relinearisation building blocks (general path; the fused key-switch kernel for F32 is below) --------------------

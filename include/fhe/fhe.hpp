@@ -20,9 +20,17 @@ struct SecurityParams {          // include/fhe.cuh:15-21
 };
 
 struct PublicKey { Polynomial *pk0; Polynomial *pk1; };      // include/fhe.cuh:41-44
+struct SecretKey { Polynomial *sk; };                         // include/fhe.cuh:47-49
 struct RelinKeys {                                            // include/fhe.cuh:52-55
-    std::vector<PublicKey *> rlk_keys;
+    std::vector<PublicKey *> rlk_keys;     // level j*K + k: (b, a) with b = -a*s + e + g*s^2, g = 2^(k*w) in limb j, 0 elsewhere
     uint32_t decomp_bits = 16;
+    // engine-side copy (NTT domain, packed for the fused key-switch kernel); built on first use
+    mutable fhe_relin_keys_t *imported = nullptr;
+    mutable const void *imported_for = nullptr;
+    RelinKeys() = default;
+    RelinKeys(const RelinKeys &) = delete;
+    RelinKeys &operator=(const RelinKeys &) = delete;
+    ~RelinKeys() { fhe_relin_keys_destroy(imported); for (PublicKey *k : rlk_keys) { if (k) { delete k->pk0; delete k->pk1; delete k; } } }
 };
 
 struct Ciphertext {                                           // include/fhe.cuh:63-69
@@ -88,9 +96,78 @@ public:
         result.level = std::max(a.level, b.level);
     }
 
-    // src/fhe.cu:226-235 is a stub that drops c2 (which breaks decryption).  Until the key-switch row
-    //  lands this keeps all three components, so no information is lost.
-    void relinearize(Ciphertext &ct, const RelinKeys &rlk) { (void)ct; (void)rlk; }
+    // src/fhe.cu:226-235 is a stub that drops c2 (which breaks decryption); docs/ARCHITECTURE.md:319-326 gives the
+    // intended algorithm, implemented here as RNS digit decomposition + key switching (fhe_ct_relinearize).
+    // With no keys (an empty RelinKeys) the ciphertext keeps its three components, so no information is lost.
+    void relinearize(Ciphertext &ct, const RelinKeys &rlk) {
+        if (ct.components.size() <= 2) return;                                              // src/fhe.cu:227
+        if (rlk.rlk_keys.empty()) return;
+        if (ct.components.size() != 3) throw std::runtime_error("FHEContext::relinearize: 3-component ciphertext expected");
+        if (!rlk.imported || rlk.imported_for != params_.rns_ntt) {
+            fhe_relin_keys_destroy(rlk.imported); rlk.imported = nullptr;
+            std::vector<const void *> kb, ka;
+            for (const PublicKey *k : rlk.rlk_keys) { kb.push_back(k->pk0->coeffs); ka.push_back(k->pk1->coeffs); }
+            check(fhe_relin_keys_create(params_.rns_ntt->handle(), &rlk.imported, rlk.decomp_bits, kb.data(), ka.data(), (uint32_t)kb.size()),
+                  "FHEContext::relinearize: key import");
+            rlk.imported_for = params_.rns_ntt;
+        }
+        check(fhe_ct_relinearize(params_.rns_ntt->handle(), rlk.imported, ct.components[0]->coeffs, ct.components[1]->coeffs,
+                                 ct.components[2]->coeffs, 1), "FHEContext::relinearize");
+        device_synchronize();
+        delete ct.components[2];
+        ct.components.resize(2);                                                            // src/fhe.cu:234
+    }
+
+    // number of key levels relinkey_gen must produce for this context: L limbs x ceil(bits(q_max) / decomp_bits) digits
+    uint32_t relin_levels(uint32_t decomp_bits) const {
+        uint32_t K = 0;
+        check(fhe_relin_num_digits(params_.rns_ntt->handle(), decomp_bits, &K), "relin_levels");
+        return K * (uint32_t)params_.rns_moduli.size();
+    }
+
+    // FHEContext::relinkey_gen (src/fhe.cu:76-111): rlk[level] = (-a*s + e + g*s^2, a).  `a` uniform and `e` small are drawn
+    // on the host from `rng` (a std::mt19937_64-like generator; the reference's device samplers are toys and out of
+    // scope); the polynomial products run on the engine.  `noise_scale` multiplies e (1 = the reference's BFV-style
+    // keys; t for BGV-style keys whose noise must vanish mod t).
+    template <class Rng>
+    void relinkey_gen(RelinKeys &rlk, const SecretKey &sk, uint32_t decomp_bits, Rng &rng, uint64_t noise_scale = 1, int noise_bound = 3) {
+        rlk.decomp_bits = decomp_bits;
+        const uint32_t L = (uint32_t)params_.rns_moduli.size(), n = params_.n, levels = relin_levels(decomp_bits), K = levels / L;
+        RNS_NTTEngine &E = *params_.rns_ntt;
+        std::unique_ptr<Polynomial> s2(new_polynomial()), tmp(new_polynomial());
+        E.multiply_rns(s2->coeffs, sk.sk->coeffs, sk.sk->coeffs);                              // s^2 (src/fhe.cu:80-81)
+        std::vector<uint256_t> h_s2((size_t)L * n), h_a((size_t)L * n), h_e((size_t)L * n), h_g((size_t)L * n);
+        device_synchronize();
+        copy_to_host(h_s2.data(), s2->coeffs, h_s2.size());
+        for (uint32_t j = 0; j < L; j++)
+            for (uint32_t k = 0; k < K; k++) {
+                PublicKey *key = new PublicKey{new_polynomial(), new_polynomial()};
+                std::fill(h_g.begin(), h_g.end(), uint256_t());
+                const uint64_t qj = params_.rns_moduli[j].limbs[0];
+                uint64_t g = 1;
+                for (uint32_t i = 0; i < k * decomp_bits; i++) g = (g << 1) % qj;           // 2^(k*w) mod q_j  (src/fhe.cu:98)
+                std::vector<int> e(n);
+                for (uint32_t x = 0; x < n; x++) e[x] = (int)(rng() % (2 * noise_bound + 1)) - noise_bound;
+                for (uint32_t l = 0; l < L; l++) {
+                    const uint64_t q = params_.rns_moduli[l].limbs[0];
+                    for (uint32_t x = 0; x < n; x++) {
+                        h_a[(size_t)l * n + x] = uint256_t(rng() % q);
+                        const uint64_t mag = (uint64_t)(e[x] < 0 ? -e[x] : e[x]) * (noise_scale % q) % q;
+                        h_e[(size_t)l * n + x] = uint256_t(e[x] < 0 ? (q - mag) % q : mag);
+                    }
+                }
+                for (uint32_t x = 0; x < n; x++)
+                    h_g[(size_t)j * n + x] = uint256_t((uint64_t)((unsigned __int128)h_s2[(size_t)j * n + x].limbs[0] * g % qj));
+                copy_to_device(key->pk1->coeffs, h_a.data(), h_a.size());
+                E.multiply_rns(tmp->coeffs, key->pk1->coeffs, sk.sk->coeffs);                 // a*s (src/fhe.cu:104)
+                copy_to_device(key->pk0->coeffs, h_e.data(), h_e.size());
+                E.sub_rns(key->pk0->coeffs, key->pk0->coeffs, tmp->coeffs);                   // e - a*s (:105)
+                copy_to_device(tmp->coeffs, h_g.data(), h_g.size());
+                E.add_rns(key->pk0->coeffs, key->pk0->coeffs, tmp->coeffs);                   // + g*s^2 (:106)
+                device_synchronize();
+                rlk.rlk_keys.push_back(key);
+            }
+    }
 
     const SchemeParams &params() const { return params_; }
 

@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <iostream>
+#include <random>
 #include <vector>
 
 #include "fhe/fhe.hpp"
@@ -166,6 +167,73 @@ static void test_fhe_multiply() {
     std::cout << "  c0, c1, c2 match schoolbook on limbs 0 and " << L - 1 << std::endl;
 }
 
+
+// FHEContext::multiply + relinearize + the decryption identity: with BGV-style ciphertexts (c0 + c1*s = m + t*e) the
+// relinearised product must decrypt to m1 (*) m2 mod t.  Key generation through FHEContext::relinkey_gen, decryption
+// here on the host (per-limb phase, centred CRT for two limbs).
+static void test_fhe_multiply_relinearize() {
+    std::cout << "Testing FHEContext::multiply + relinearize (decrypts to the plaintext product)..." << std::endl;
+    const uint32_t N = 2048; const uint64_t t = 257;
+    SecurityParams sp{128, N, 60, 3.2f, 64};                       // log_q = 60 -> 2 limbs of 30 bits
+    FHEContext ctx(sp);
+    const SchemeParams &P = ctx.params();
+    const uint32_t L = (uint32_t)P.rns_moduli.size();
+    REQUIRE(L == 2);
+    const uint64_t q0 = P.rns_moduli[0].limbs[0], q1 = P.rns_moduli[1].limbs[0];
+    std::mt19937_64 rng(42);
+    // secret key, plaintexts, errors
+    std::vector<int> s(N); for (auto &v : s) v = (int)(rng() % 3) - 1;
+    std::vector<uint64_t> m1(N), m2(N); for (uint32_t i = 0; i < N; i++) { m1[i] = rng() % t; m2[i] = rng() % t; }
+    auto to_rns = [&](const std::vector<long long> &v) {
+        std::vector<uint256_t> out((size_t)L * N);
+        for (uint32_t l = 0; l < L; l++) { const long long q = (long long)P.rns_moduli[l].limbs[0]; for (uint32_t i = 0; i < N; i++) out[(size_t)l * N + i] = uint256_t((uint64_t)(((v[i] % q) + q) % q)); }
+        return out;
+    };
+    SecretKey sk{ctx.new_polynomial()};
+    { std::vector<long long> sv(s.begin(), s.end()); auto r = to_rns(sv); copy_to_device(sk.sk->coeffs, r.data(), r.size()); }
+    RNS_NTTEngine &E = *P.rns_ntt;
+    auto encrypt = [&](const std::vector<uint64_t> &m, Ciphertext &ct) {       // c1 = a uniform, c0 = m + t*e - a*s
+        Polynomial *c0 = ctx.new_polynomial(), *c1 = ctx.new_polynomial();
+        std::unique_ptr<Polynomial> as(ctx.new_polynomial());
+        std::vector<uint256_t> a((size_t)L * N);
+        for (uint32_t l = 0; l < L; l++) for (uint32_t i = 0; i < N; i++) a[(size_t)l * N + i] = uint256_t(rng() % P.rns_moduli[l].limbs[0]);
+        std::vector<long long> me(N); for (uint32_t i = 0; i < N; i++) me[i] = (long long)m[i] + (long long)t * ((long long)(rng() % 7) - 3);
+        auto r = to_rns(me);
+        copy_to_device(c1->coeffs, a.data(), a.size()); copy_to_device(c0->coeffs, r.data(), r.size());
+        E.multiply_rns(as->coeffs, c1->coeffs, sk.sk->coeffs);
+        E.sub_rns(c0->coeffs, c0->coeffs, as->coeffs);
+        device_synchronize();
+        ct.components = {c0, c1};
+    };
+    Ciphertext A, B, C;
+    encrypt(m1, A); encrypt(m2, B);
+    RelinKeys rlk;
+    ctx.relinkey_gen(rlk, sk, 16, rng, /*noise_scale=*/t);
+    REQUIRE(rlk.rlk_keys.size() == ctx.relin_levels(16) && rlk.rlk_keys.size() == 4);
+    ctx.multiply(C, A, B, rlk);
+    REQUIRE(C.components.size() == 2);                                       // relinearised (src/fhe.cu:234)
+    // decrypt: phase = c0 + c1*s per limb, CRT to the centred integer, mod t
+    std::unique_ptr<Polynomial> ph(ctx.new_polynomial());
+    E.multiply_rns(ph->coeffs, C.components[1]->coeffs, sk.sk->coeffs);
+    E.add_rns(ph->coeffs, ph->coeffs, C.components[0]->coeffs);
+    device_synchronize();
+    std::vector<uint256_t> h((size_t)L * N); copy_to_host(h.data(), ph->coeffs, h.size());
+    const unsigned __int128 Q = (unsigned __int128)q0 * q1;
+    uint64_t q0inv_mod_q1 = 1; { uint64_t b = q0 % q1, e = q1 - 2; unsigned __int128 acc = 1, bb = b; while (e) { if (e & 1) acc = acc * bb % q1; bb = bb * bb % q1; e >>= 1; } q0inv_mod_q1 = (uint64_t)acc; }
+    auto want = schoolbook_negacyclic(m1, m2, t);
+    for (uint32_t i = 0; i < N; i++) {
+        const uint64_t r0 = h[i].limbs[0], r1 = h[(size_t)N + i].limbs[0];
+        // x = r0 + q0 * ((r1 - r0) * q0^-1 mod q1)
+        const uint64_t diff = (r1 + q1 - r0 % q1) % q1;
+        unsigned __int128 x = (unsigned __int128)r0 + (unsigned __int128)q0 * (uint64_t)((unsigned __int128)diff * q0inv_mod_q1 % q1);
+        long long mt;
+        if (x > Q / 2) { unsigned __int128 neg = Q - x; mt = (long long)((t - (uint64_t)(neg % t)) % t); } else mt = (long long)(uint64_t)(x % t);
+        REQUIRE((uint64_t)mt == want[i]);
+    }
+    delete sk.sk;
+    std::cout << "  Dec(relin(Enc(m1) x Enc(m2))) == m1 (*) m2 mod " << t << " on all " << N << " coefficients" << std::endl;
+}
+
 // tests/test_fhe.cu:275-318 shape (N = 8192), timing the multiply path instead of encrypt
 static void benchmark_multiply() {
     std::cout << "Benchmark: ciphertext tensor product, N = 8192, log_q = 120" << std::endl;
@@ -195,6 +263,7 @@ int main(int argc, char **argv) {
     test_ntt_transform();
     test_polynomial_multiplication();
     test_fhe_multiply();
+    test_fhe_multiply_relinearize();
     benchmark_multiply();
     std::cout << "ALL PASSED" << std::endl;
     return 0;

@@ -341,6 +341,22 @@ def test_relinearize_matches_oracle(eng, oracle, n, spec, w, batch):
         e.import_relin_keys(w, dkb[:-1], dka[:-1])
 
 
+def test_relinearize_general_path_on_32bit_moduli(eng, oracle, monkeypatch):
+    """The unfused composition (digit embedding, batched NTT, MAC) must agree with the fused key-switch kernel."""
+    monkeypatch.setenv("FHE_HIP_NO_FUSED_KEYSWITCH", "1")
+    n, w, batch = 4096, 16, 2
+    moduli = nm.ntt_primes(30, n, 3); L = 3
+    e = eng.RnsNttEngine(n, moduli); rp = oracle.RnsPlan(n, moduli)
+    K = e.relin_num_digits(w)
+    kb = _random_keys(moduli, n, L * K, 300); ka = _random_keys(moduli, n, L * K, 700)
+    c0, c1, c2 = (rns_poly(s, moduli, n, batch) for s in (61, 62, 63))
+    rk = e.import_relin_keys(w, [_up(eng, k) for k in kb], [_up(eng, k) for k in ka])
+    d0, d1, d2 = _up(eng, c0), _up(eng, c1), _up(eng, c2)
+    e.relinearize(rk, d0, d1, d2, batch)
+    w0, w1 = rp.relinearize(w, c0, c1, c2, kb, ka, threads=8)
+    assert np.array_equal(d0.download(c0.shape), w0) and np.array_equal(d1.download(c0.shape), w1)
+
+
 def test_reference_fhe_scenario_on_gpu(eng, oracle):
     """tests/test_fhe.cu:169-273 at its own size (N = 4096, t = 65537) on the multiply path: encrypt on the host (toy BGV,
     test code), tensor product + relinearisation on the GPU, decrypt on the host: 15 60 135 240 and 8 16 24 32."""
