@@ -40,6 +40,9 @@ def parse():
     ap.add_argument("--limbs", type=int, default=4)
     ap.add_argument("--bits", type=int, default=30, help="bit length of each RNS prime (30 = log_q 120 / 4 limbs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl (= RCCL over xGMI) on a multi-GPU node; gloo only to rehearse the N > 1 path on a one-GPU box")
+    ap.add_argument("--device-override", type=int, default=None, help="rehearsal only: put every rank on this device")
     ap.add_argument("--op", choices=["multiply", "fwdinv", "ct", "relin", "ctrelin"], default="multiply",
                     help="multiply = fused polymul (the headline, configs[1]); fwdinv = forward+inverse NTT pair; "
                          "ct = ciphertext tensor product; relin = key switching of c2 into (c0, c1); "
@@ -112,12 +115,15 @@ def main():
     pkg = importlib.import_module("gpu-homomorphic-encryption_amd")
     sharding = importlib.import_module("gpu-homomorphic-encryption_amd.sharding")
     if world > 1:
-        dist = sharding.init_process_group("nccl")     # RCCL: barriers + max-over-ranks only, no payload collective
+        if args.device_override is not None:
+            os.environ["LOCAL_RANK"] = str(args.device_override); local_rank = args.device_override
+        dist = sharding.init_process_group(args.dist_backend)   # RCCL: barriers + max-over-ranks only, no payload collective
     if pkg.device_count() < 1:
         raise SystemExit("bench.py: no HIP device; the engine has no CPU fallback")
     if world > 1:
         rc = pkg.lib().fhe_hip_set_device(local_rank)
         assert rc == 0, pkg.lib().fhe_hip_last_error()
+    red_dev = "cuda" if (dist is not None and args.dist_backend == "nccl") else "cpu"
 
     n, L, B = args.n, args.limbs, args.batch
     moduli = pkg.find_ntt_primes(args.bits, n, L)
@@ -182,7 +188,7 @@ def main():
             dist.barrier()
         wall = time.perf_counter() - t0
         ev_ms = timer.elapsed_ms()
-        wall, ev_ms = sharding.max_over_ranks(dist, [wall, ev_ms], device="cuda" if dist is not None else "cpu")
+        wall, ev_ms = sharding.max_over_ranks(dist, [wall, ev_ms], device=red_dev)
         return wall, ev_ms
 
     wall, ev_ms = timed(step, args.steps, args.warmup)
