@@ -388,3 +388,78 @@ def test_reference_fhe_scenario_on_gpu(eng, oracle):
     e.poly_add(s0, d[0], d[2], 1); e.poly_add(s1, d[1], d[3], 1)
     summed = [bgv_toy.from_limb_array(x.download(shape)) for x in (s0, s1)]
     assert S.slot_decode(S.decrypt(summed))[:4] == [8, 16, 24, 32]
+
+
+# ------------------------------------------------------------------------------------ robustness
+def test_small_transform_sizes_and_many_limbs(eng, oracle):
+    """n from 8 upward (general path below 2^11) and an RNS basis of 12 limbs."""
+    for n in (8, 16, 128, 512):
+        q = nm.ntt_primes(20, n, 1)[0]
+        e = eng.NttEngine(n, q); p = oracle.Plan(n, q)
+        a = rns_poly(71, [q], n, 3)[:, 0]; b = rns_poly(72, [q], n, 3)[:, 0]
+        dA, dB, dR = _up(eng, a), _up(eng, b), eng.DeviceBuffer(a.nbytes)
+        e.multiply(dR, dA, dB, 3)
+        got = dR.download(a.shape)
+        for i in range(3):
+            assert np.array_equal(got[i], p.polymul(np.ascontiguousarray(a[i]), np.ascontiguousarray(b[i])))
+    n, L = 2048, 12
+    moduli = nm.ntt_primes(30, n, L)
+    e = eng.RnsNttEngine(n, moduli); rp = oracle.RnsPlan(n, moduli)
+    a = rns_poly(73, moduli, n, 2); b = rns_poly(74, moduli, n, 2)
+    dR = eng.DeviceBuffer(a.nbytes)
+    e.multiply(dR, _up(eng, a), _up(eng, b), 2)
+    assert np.array_equal(dR.download(a.shape), rp.polymul(a, b, threads=8))
+
+
+def test_mixed_width_basis_uses_the_widest_class(eng, oracle):
+    """A basis mixing a 30-bit and a 40-bit prime runs on the FP64 path; 30-bit + 60-bit on the 64-bit integer path."""
+    n = 4096
+    for moduli, width in ((nm.ntt_primes(30, n, 1) + nm.ntt_primes(40, n, 1), 3), (nm.ntt_primes(30, n, 1) + nm.ntt_primes(60, n, 1), 2)):
+        e = eng.RnsNttEngine(n, moduli); rp = oracle.RnsPlan(n, moduli)
+        assert e.width_class == width
+        a = rns_poly(75, moduli, n, 2); b = rns_poly(76, moduli, n, 2)
+        dR = eng.DeviceBuffer(a.nbytes)
+        e.multiply(dR, _up(eng, a), _up(eng, b), 2)
+        assert np.array_equal(dR.download(a.shape), rp.polymul(a, b, threads=8))
+
+
+def test_general_path_batches_beyond_one_grid_dimension(eng, oracle):
+    """The full-width path splits launches at 65535 polynomials (grid.y limit): 70000 polynomials of n = 8."""
+    n = 8; q = nm.ntt_primes(70, n, 1)[0]; batch = 70000
+    e = eng.NttEngine(n, q); p = oracle.Plan(n, q)
+    assert e.width_class == 4
+    a = rns_poly(77, [q], n, batch)[:, 0]
+    d = _up(eng, a); e.forward(d, batch)
+    got = d.download(a.shape)
+    for i in (0, 65534, 65535, 65536, 69999):
+        assert np.array_equal(got[i], p.forward(np.ascontiguousarray(a[i])))
+    e.inverse(d, batch)
+    assert np.array_equal(d.download(a.shape), a)
+
+
+def test_two_engines_and_caller_stream_interleave(eng, oracle):
+    """Two engines (different moduli) used alternately on their own streams, results downloaded after one sync."""
+    n = 8192
+    m1, m2 = nm.ntt_primes(30, n, 2), nm.ntt_primes(29, n, 2)
+    e1, e2 = eng.RnsNttEngine(n, m1), eng.RnsNttEngine(n, m2)
+    r1, r2 = oracle.RnsPlan(n, m1), oracle.RnsPlan(n, m2)
+    a1, b1 = rns_poly(81, m1, n, 4), rns_poly(82, m1, n, 4)
+    a2, b2 = rns_poly(83, m2, n, 4), rns_poly(84, m2, n, 4)
+    d = [_up(eng, x) for x in (a1, b1, a2, b2)]
+    o1, o2 = eng.DeviceBuffer(a1.nbytes), eng.DeviceBuffer(a2.nbytes)
+    for _ in range(3):
+        e1.multiply(o1, d[0], d[1], 4); e2.multiply(o2, d[2], d[3], 4)
+    eng.capi.sync()
+    assert np.array_equal(o1.download(a1.shape), r1.polymul(a1, b1, threads=8))
+    assert np.array_equal(o2.download(a2.shape), r2.polymul(a2, b2, threads=8))
+
+
+def test_repeated_calls_are_deterministic(eng):
+    n = 8192; moduli = nm.ntt_primes(30, n, 4)
+    e = eng.RnsNttEngine(n, moduli)
+    a = rns_poly(91, moduli, n, 64); b = rns_poly(92, moduli, n, 64)
+    dA, dB, dR = _up(eng, a), _up(eng, b), eng.DeviceBuffer(a.nbytes)
+    e.multiply(dR, dA, dB, 64); first = dR.download(a.shape).copy()
+    for _ in range(5):
+        dR.zero(); e.multiply(dR, dA, dB, 64)
+        assert np.array_equal(dR.download(a.shape), first)
