@@ -73,6 +73,8 @@ def lib():
         "fhe_rns_poly_sub": ([vp, vp, vp, vp, u32], ci),
         "fhe_ct_multiply": ([vp] * 8 + [u32], ci),
         "fhe_rns_check_canonical": ([vp, vp, u32], ci),
+        "fhe_rns_to_rns": ([vp, vp, vp, u32], ci),
+        "fhe_rns_from_rns": ([vp, vp, vp, u32], ci),
         "fhe_relin_num_digits": ([vp, u32, P(u32)], ci),
         "fhe_relin_keys_create": ([vp, P(vp), u32, P(vp), P(vp), u32], ci),
         "fhe_relin_keys_destroy": ([vp], ci),
@@ -279,6 +281,12 @@ class RnsNttEngine:
     def ct_multiply(self, d_c0, d_c1, d_c2, d_a0, d_a1, d_b0, d_b1, batch=1):
         _check(lib().fhe_ct_multiply(self.h, _ptr(d_c0), _ptr(d_c1), _ptr(d_c2), _ptr(d_a0), _ptr(d_a1), _ptr(d_b0),
                                      _ptr(d_b1), batch))
+
+    def to_rns(self, d_rns, d_values, batch=1):
+        _check(lib().fhe_rns_to_rns(self.h, _ptr(d_rns), _ptr(d_values), batch))
+
+    def from_rns(self, d_values, d_rns, batch=1):
+        _check(lib().fhe_rns_from_rns(self.h, _ptr(d_values), _ptr(d_rns), batch))
 
     def relin_num_digits(self, decomp_bits):
         k = ctypes.c_uint32(0); _check(lib().fhe_relin_num_digits(self.h, decomp_bits, ctypes.byref(k))); return k.value

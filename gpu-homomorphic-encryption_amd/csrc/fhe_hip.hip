@@ -188,6 +188,9 @@ struct fhe_rns_ntt {
     void *d_ws = nullptr; size_t ws_bytes = 0;
     uint32_t *d_flag = nullptr;
     std::vector<U256> moduli;
+    void *d_crt = nullptr;               // CrtLimb[L], built on first use of to_rns / from_rns (owned by d_tables)
+    fhe_dev::CrtBig crt_big;
+    int crt_state = 0;                   // 0 = not built, 1 = ready, -1 = Q too large for from_rns (to_rns still fine)
 };
 struct fhe_ntt { fhe_rns_ntt *impl; };
 
@@ -720,6 +723,72 @@ extern "C" int fhe_ct_relinearize(fhe_rns_ntt_t *h, const fhe_relin_keys_t *rk, 
         if ((rc = do_ew<1>(h, c1, c1, acc1, nb, "relin add"))) return rc;
     }
     return FHE_OK;
+}
+
+
+// ------------------------------------------------------------------------------------------------------
+// RNS entry / exit
+// ------------------------------------------------------------------------------------------------------
+static bool mul_checked(U256 &r, const U256 &a, const U256 &b) {      // r = a*b, false on overflow beyond 256 bits
+    uint64_t t[8] = {0};
+    for (int i = 0; i < 4; i++) {
+        uint64_t carry = 0;
+        for (int j = 0; j < 4; j++) {
+            fhe_host::u128 acc = (fhe_host::u128)a.w[i] * b.w[j] + t[i + j] + carry;
+            t[i + j] = (uint64_t)acc; carry = (uint64_t)(acc >> 64);
+        }
+        t[i + 4] = carry;
+    }
+    std::memcpy(r.w, t, 32);
+    return !(t[4] | t[5] | t[6] | t[7]);
+}
+static int ensure_crt(fhe_rns_ntt *h) {
+    if (h->crt_state) return FHE_OK;
+    const uint32_t L = h->L;
+    U256 Q(1); bool fits = true;
+    for (uint32_t l = 0; l < L && fits; l++) { U256 t; fits = mul_checked(t, Q, h->moduli[l]); Q = t; }
+    fits = fits && !(Q.w[3] >> 63);
+    std::vector<fhe_dev::CrtLimb> limbs(L);
+    std::memset(limbs.data(), 0, L * sizeof(fhe_dev::CrtLimb));
+    for (uint32_t l = 0; l < L; l++) {
+        fhe_host::Mod M(h->moduli[l]);
+        std::memcpy(limbs[l].q.l, M.q.w, 32); std::memcpy(limbs[l].r2.l, M.r2.w, 32); limbs[l].inv0 = M.inv0;
+    }
+    if (fits) {
+        fhe_host::Mod MQ(Q);
+        for (uint32_t l = 0; l < L; l++) {
+            U256 Mi(1);
+            for (uint32_t k = 0; k < L; k++) if (k != l) { U256 t; mul_checked(t, Mi, h->moduli[k]); Mi = t; }
+            fhe_host::Mod M(h->moduli[l]);
+            U256 qm2; fhe_host::sub_to(qm2, M.q, U256(2));
+            U256 minv_m = M.pow_m(M.to_mont(M.reduce(Mi)), qm2);                 // ((Q/q)^-1 mod q) * R
+            U256 Mi_mQ = MQ.to_mont(Mi);
+            std::memcpy(limbs[l].minv_m.l, minv_m.w, 32); std::memcpy(limbs[l].Mi_mQ.l, Mi_mQ.w, 32);
+        }
+        std::memcpy(h->crt_big.Q.l, Q.w, 32); h->crt_big.inv0 = MQ.inv0; h->crt_big._pad = 0;
+    }
+    int rc = upload(h, limbs, &h->d_crt); if (rc) return rc;
+    h->crt_state = fits ? 1 : -1;
+    return FHE_OK;
+}
+extern "C" int fhe_rns_to_rns(fhe_rns_ntt_t *h, void *d_rns, const void *d_values, uint32_t batch) {
+    int rc = check_call(h, batch, "to_rns"); if (rc) return rc;
+    if (!d_rns || !d_values || d_rns == d_values) return fail(FHE_ERR_INVALID_ARG, "to_rns: null or aliased argument");
+    if ((rc = ensure_crt(h))) return rc;
+    const size_t count = (size_t)batch * h->n;
+    hipLaunchKernelGGL(fhe_dev::to_rns_kernel, dim3(ew_grid(count)), dim3(256), 0, h->stream, (fhe_dev::u256 *)d_rns, (const fhe_dev::u256 *)d_values,
+                       (const fhe_dev::CrtLimb *)h->d_crt, h->L, h->log_n, count);
+    return post_launch(h->stream, "to_rns_kernel");
+}
+extern "C" int fhe_rns_from_rns(fhe_rns_ntt_t *h, void *d_values, const void *d_rns, uint32_t batch) {
+    int rc = check_call(h, batch, "from_rns"); if (rc) return rc;
+    if (!d_rns || !d_values || d_rns == d_values) return fail(FHE_ERR_INVALID_ARG, "from_rns: null or aliased argument");
+    if ((rc = ensure_crt(h))) return rc;
+    if (h->crt_state < 0) return fail(FHE_ERR_UNSUPPORTED, "from_rns: the product of the moduli must be below 2^255 to fit a 256-bit container");
+    const size_t count = (size_t)batch * h->n;
+    hipLaunchKernelGGL(fhe_dev::from_rns_kernel, dim3(ew_grid(count)), dim3(256), 0, h->stream, (fhe_dev::u256 *)d_values, (const fhe_dev::u256 *)d_rns,
+                       (const fhe_dev::CrtLimb *)h->d_crt, h->crt_big, h->L, h->log_n, count);
+    return post_launch(h->stream, "from_rns_kernel");
 }
 
 // ------------------------------------------------------------------------------------------------------

@@ -200,4 +200,46 @@ relin_mac256_kernel(u256 *__restrict__ acc0, u256 *__restrict__ acc1, const u256
     }
 }
 
+// ---- RNS entry / exit (RNS_NTTEngine::to_rns / from_rns, include/ntt.cuh:114-117; src/rns.cu:93-141 are placeholders) ---
+// Container-level operations, independent of the width class of the transforms.
+struct CrtLimb {
+    u256 q, r2;          // modulus, R^2 mod q
+    u256 minv_m;         // ((Q/q)^-1 mod q) * R mod q
+    u256 Mi_mQ;          // (Q/q) * R mod Q          (Montgomery form with respect to Q)
+    uint64_t inv0, _pad;
+};
+struct CrtBig { u256 Q; uint64_t inv0, _pad; };
+
+// rns[b][l][x] = values[b][x] mod q_l : mont(mont(v, R^2), 1) is exact for ANY 256-bit v (the sum before the final
+// subtraction is below 2q).  One lane per (b, x); the L residues are produced from one load of the value.
+__global__ void __launch_bounds__(256)
+to_rns_kernel(u256 *__restrict__ rns, const u256 *__restrict__ values, const CrtLimb *__restrict__ limbs, uint32_t L, uint32_t log_n, size_t count) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x, n = (size_t)1 << log_n;
+    u256 one; one.l[0] = 1; one.l[1] = one.l[2] = one.l[3] = 0;
+    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < count; g += stride) {
+        const u256 v = load_u256(values + g);
+        const size_t b = g >> log_n, x = g & (n - 1);
+        for (uint32_t l = 0; l < L; l++) {
+            const CrtLimb &P = limbs[l];
+            store_u256(rns + (b * L + l) * n + x, mont_mul(mont_mul(v, P.r2, P.q, P.inv0), one, P.q, P.inv0));
+        }
+    }
+}
+// values[b][x] = sum_l [r_l * (Q/q_l)^-1]_{q_l} * (Q/q_l) mod Q, accumulated with the 256-bit Montgomery primitives modulo Q.
+__global__ void __launch_bounds__(256)
+from_rns_kernel(u256 *__restrict__ values, const u256 *__restrict__ rns, const CrtLimb *__restrict__ limbs, const CrtBig big, uint32_t L,
+                uint32_t log_n, size_t count) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x, n = (size_t)1 << log_n;
+    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < count; g += stride) {
+        const size_t b = g >> log_n, x = g & (n - 1);
+        u256 acc; acc.l[0] = acc.l[1] = acc.l[2] = acc.l[3] = 0;
+        for (uint32_t l = 0; l < L; l++) {
+            const CrtLimb &P = limbs[l];
+            const u256 t = mont_mul(load_u256(rns + (b * L + l) * n + x), P.minv_m, P.q, P.inv0);
+            acc = add_mod(acc, mont_mul(t, P.Mi_mQ, big.Q, big.inv0), big.Q);
+        }
+        store_u256(values + g, acc);
+    }
+}
+
 }  // namespace fhe_dev

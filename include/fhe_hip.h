@@ -137,6 +137,15 @@ int fhe_rns_poly_sub(fhe_rns_ntt_t *h, void *d_r, const void *d_a, const void *d
  * reference's 8 + 4 (results identical: modular arithmetic is exact). */
 int fhe_ct_multiply(fhe_rns_ntt_t *h, void *d_c0, void *d_c1, void *d_c2,
                     const void *d_a0, const void *d_a1, const void *d_b0, const void *d_b1, uint32_t batch);
+/* ---- RNS entry / exit ------------------------------------------------------------------------------ */
+/* RNS_NTTEngine::to_rns (include/ntt.cuh:114; RNSContext::to_rns src/rns.cu:56-61, kernel :93-115 is a placeholder that
+ * copies the value): d_rns[b][l][x] = d_values[b][x] mod q_l for ANY 256-bit value; d_values is [batch][n], d_rns is
+ * [batch][L][n] (limb-major like every other buffer of this engine). */
+int fhe_rns_to_rns(fhe_rns_ntt_t *h, void *d_rns, const void *d_values, uint32_t batch);
+/* RNS_NTTEngine::from_rns (include/ntt.cuh:117; from_rns_crt_kernel src/rns.cu:117-141 writes zero): Chinese remainder
+ * reconstruction into [0, Q), Q = prod q_l.  Needs Q < 2^255 (FHE_ERR_UNSUPPORTED otherwise). */
+int fhe_rns_from_rns(fhe_rns_ntt_t *h, void *d_values, const void *d_rns, uint32_t batch);
+
 /* ---- relinearisation / key switching ------------------------------------------ */
 /* RelinKeys (include/fhe.cuh:52-55) as produced by FHEContext::relinkey_gen (src/fhe.cu:76-111):
  * key pairs (b, a) with b = -a*s + e + g*s^2, one per decomposition level.  In the RNS representation every residue

@@ -476,3 +476,70 @@ int orc_relinearize(orc_plan *const *plans, uint32_t L, uint32_t decomp_bits, or
     free(kb); free(ka);
     return threads;
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* values mod q through the Montgomery primitive: mont(mont(x, R^2), 1) = x mod q for any 256-bit x
+ * (u = (x*R2 + m*q)/R < 2q, one conditional subtraction). */
+void orc_to_rns(orc_plan *const *plans, uint32_t L, orc_u256 *rns, const orc_u256 *values, uint32_t batch) {
+    const uint32_t n = plans[0]->n;
+    for (uint32_t b = 0; b < batch; b++)
+        for (uint32_t l = 0; l < L; l++) {
+            const orc_plan *p = plans[l];
+            for (uint32_t x = 0; x < n; x++) {
+                orc_u256 t;
+                orc_mont_mul(&t, &values[(size_t)b * n + x], &p->r2, &p->q, p->inv0);
+                from_mont(p, &rns[((size_t)b * L + l) * n + x], &t);
+            }
+        }
+}
+
+/* a*b for multi-limb a (4 limbs) and a 256-bit b, low 256 bits; returns 0 on overflow. */
+static int mul256_checked(orc_u256 *r, const orc_u256 *a, const orc_u256 *b) {
+    uint64_t t[8] = {0};
+    for (int i = 0; i < 4; i++) {
+        uint64_t carry = 0;
+        for (int j = 0; j < 4; j++) {
+            u128 acc = (u128)a->limbs[i] * b->limbs[j] + t[i + j] + carry;
+            t[i + j] = (uint64_t)acc; carry = (uint64_t)(acc >> 64);
+        }
+        t[i + 4] = carry;
+    }
+    memcpy(r->limbs, t, 32);
+    return !(t[4] | t[5] | t[6] | t[7]);
+}
+
+int orc_from_rns(orc_plan *const *plans, uint32_t L, orc_u256 *values, const orc_u256 *rns, uint32_t batch) {
+    const uint32_t n = plans[0]->n;
+    /* Q and the CRT constants, with the arithmetic mod Q done by a throw-away plan-like context */
+    orc_u256 Q = u256_from(1);
+    for (uint32_t l = 0; l < L; l++) { orc_u256 t; if (!mul256_checked(&t, &Q, &plans[l]->q)) return -1; Q = t; }
+    if (Q.limbs[3] >> 63) return -1;
+    orc_plan big; memset(&big, 0, sizeof big);
+    big.q = Q; big.inv0 = orc_mont_inverse(&Q);
+    { orc_u256 x = u256_from(1), t; for (int i = 0; i < 512; i++) { orc_add_mod(&t, &x, &x, &Q); x = t; if (i == 255) big.r1 = x; } big.r2 = x; }
+    orc_u256 *Mi_m = (orc_u256 *)malloc(L * sizeof(orc_u256)), *inv_m = (orc_u256 *)malloc(L * sizeof(orc_u256));
+    for (uint32_t l = 0; l < L; l++) {
+        orc_u256 Mi = u256_from(1), t;
+        for (uint32_t k = 0; k < L; k++) if (k != l) { mul256_checked(&t, &Mi, &plans[k]->q); Mi = t; }
+        to_mont(&big, &Mi_m[l], &Mi);                                   /* M_l * R_Q mod Q */
+        const orc_plan *p = plans[l];
+        orc_u256 mi_mod, mi_m, e = p->q; e.limbs[0] -= 2;
+        orc_mont_mul(&t, &Mi, &p->r2, &p->q, p->inv0); mi_m = t;         /* (M_l mod q_l) * R, any 256-bit M_l */
+        (void)mi_mod;
+        pow_mont(p, &inv_m[l], &mi_m, &e);                              /* (M_l^-1 mod q_l) * R */
+    }
+    for (uint32_t b = 0; b < batch; b++)
+        for (uint32_t x = 0; x < n; x++) {
+            orc_u256 acc = u256_from(0);
+            for (uint32_t l = 0; l < L; l++) {
+                const orc_plan *p = plans[l];
+                orc_u256 tl, term, s;
+                orc_mont_mul(&tl, &rns[((size_t)b * L + l) * n + x], &inv_m[l], &p->q, p->inv0);   /* [r_l * M_l^-1]_{q_l} */
+                orc_mont_mul(&term, &tl, &Mi_m[l], &Q, big.inv0);                                 /* * M_l mod Q */
+                orc_add_mod(&s, &acc, &term, &Q); acc = s;
+            }
+            values[(size_t)b * n + x] = acc;
+        }
+    free(Mi_m); free(inv_m);
+    return 0;
+}

@@ -110,6 +110,12 @@ int orc_ct_multiply(orc_plan *const *plans, uint32_t L, orc_u256 *c0, orc_u256 *
 uint32_t orc_relin_num_digits(orc_plan *const *plans, uint32_t L, uint32_t decomp_bits);
 int orc_relinearize(orc_plan *const *plans, uint32_t L, uint32_t decomp_bits, orc_u256 *c0, orc_u256 *c1, const orc_u256 *c2,
                     const orc_u256 *const *keys_b, const orc_u256 *const *keys_a, uint32_t batch, int threads);
+/* RNS entry / exit -- RNS_NTTEngine::to_rns / from_rns (include/ntt.cuh:114-117, undefined in the reference) and
+ * RNSContext::to_rns / from_rns (src/rns.cu:56-68; their kernels are placeholders: to_rns_kernel copies the value,
+ * from_rns_crt_kernel writes zero, src/rns.cu:93-141).  Intended maths: residues[l][x] = values[x] mod q_l (limb-major,
+ * SURVEY D12) and the CRT reconstruction values[x] = sum_l [r_l * (Q/q_l)^-1]_{q_l} * (Q/q_l) mod Q, Q = prod q_l < 2^255. */
+void orc_to_rns(orc_plan *const *plans, uint32_t L, orc_u256 *rns, const orc_u256 *values, uint32_t batch);
+int orc_from_rns(orc_plan *const *plans, uint32_t L, orc_u256 *values, const orc_u256 *rns, uint32_t batch);
 int orc_max_threads(void);
 
 #ifdef __cplusplus

@@ -72,6 +72,8 @@ def lib():
             "orc_rns_polymul": (ci, [ctypes.POINTER(vp), u32, P, P, P, u32, ci]),
             "orc_ct_multiply": (ci, [ctypes.POINTER(vp), u32] + [P] * 7 + [u32, ci]),
             "orc_max_threads": (ci, []),
+            "orc_to_rns": (None, [ctypes.POINTER(vp), u32, P, P, u32]),
+            "orc_from_rns": (ci, [ctypes.POINTER(vp), u32, P, P, u32]),
             "orc_relin_num_digits": (u32, [ctypes.POINTER(vp), u32, u32]),
             "orc_relinearize": (ci, [ctypes.POINTER(vp), u32, u32, P, P, P, ctypes.POINTER(P), ctypes.POINTER(P), u32, ci]),
         }
@@ -287,6 +289,25 @@ def _rns_num_digits(self, decomp_bits):
     return int(lib().orc_relin_num_digits(self._arr, self.L, decomp_bits))
 
 
+def _rns_to_rns(self, values):
+    """[batch][n] 256-bit integers -> [batch][L][n] residues."""
+    _chk(values); batch = values.size // (4 * self.n)
+    out = np.empty((batch, self.L, self.n, 4), np.uint64)
+    lib().orc_to_rns(self._arr, self.L, _p(out), _p(np.ascontiguousarray(values)), batch); return out
+
+
+def _rns_from_rns(self, rns):
+    """[batch][L][n] residues -> [batch][n] integers in [0, Q) (CRT)."""
+    batch = self._batch(rns)
+    out = np.empty((batch, self.n, 4), np.uint64)
+    rc = lib().orc_from_rns(self._arr, self.L, _p(out), _p(np.ascontiguousarray(rns)), batch)
+    if rc != 0:
+        raise ValueError("oracle: product of the moduli must stay below 2^255")
+    return out
+
+
+RnsPlan.to_rns = _rns_to_rns
+RnsPlan.from_rns = _rns_from_rns
 RnsPlan.relinearize = _rns_relin
 RnsPlan.num_digits = _rns_num_digits
 

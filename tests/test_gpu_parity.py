@@ -463,3 +463,42 @@ def test_repeated_calls_are_deterministic(eng):
     for _ in range(5):
         dR.zero(); e.multiply(dR, dA, dB, 64)
         assert np.array_equal(dR.download(a.shape), first)
+
+
+# ------------------------------------------------------------------------------------ RNS entry / exit (row a18)
+@pytest.mark.parametrize("n,bits,L", [(8192, 30, 4), (2048, 60, 4), (64, 120, 2), (1024, 30, 8), (256, 250, 1), (4096, 40, 6)])
+def test_to_rns_from_rns_match_oracle(eng, oracle, n, bits, L):
+    import random as _r
+    moduli = nm.ntt_primes(bits, n, L)
+    Q = 1
+    for q in moduli:
+        Q *= q
+    e = eng.RnsNttEngine(n, moduli); rp = oracle.RnsPlan(n, moduli)
+    rng = _r.Random(n + L); batch = 2
+    vals = [rng.randrange(Q) for _ in range(batch * n - 3)] + [0, Q - 1, 1]
+    V = oracle.to_limbs(vals).reshape(batch, n, 4)
+    dV = _up(eng, V); dR = eng.DeviceBuffer(batch * L * n * 32)
+    e.to_rns(dR, dV, batch)
+    R = dR.download((batch, L, n, 4))
+    assert np.array_equal(R, rp.to_rns(V))
+    dBack = eng.DeviceBuffer(V.nbytes)
+    e.from_rns(dBack, dR, batch)
+    assert np.array_equal(dBack.download(V.shape), V) and np.array_equal(dBack.download(V.shape), rp.from_rns(R))
+    # arbitrary 256-bit inputs wrap modulo each prime
+    big = oracle.to_limbs([rng.getrandbits(256) for _ in range(batch * n)]).reshape(batch, n, 4)
+    e.to_rns(dR, _up(eng, big), batch)
+    assert np.array_equal(dR.download((batch, L, n, 4)), rp.to_rns(big))
+    # CRT of a product computed limb-wise equals the product of the integers reduced mod (x^n + 1, Q): spot-check coefficient 0
+    a = rns_poly(95, moduli, n, 1); b = rns_poly(96, moduli, n, 1)
+    dP = eng.DeviceBuffer(a.nbytes); e.multiply(dP, _up(eng, a), _up(eng, b), 1)
+    dC = eng.DeviceBuffer(n * 32); e.from_rns(dC, dP, 1)
+    assert np.array_equal(dC.download((1, n, 4)), rp.from_rns(rp.polymul(a, b, threads=8)))
+
+
+def test_from_rns_rejects_oversized_basis(eng):
+    n = 2048; e = eng.RnsNttEngine(n, nm.ntt_primes(60, n, 5))
+    buf = eng.DeviceBuffer(5 * n * 32); out = eng.DeviceBuffer(n * 32)
+    with pytest.raises(eng.FheError) as ei:
+        e.from_rns(out, buf, 1)
+    assert ei.value.code == -5
+    e.to_rns(buf, out, 1)          # to_rns has no such limit

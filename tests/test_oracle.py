@@ -266,3 +266,33 @@ def test_reference_fhe_expectation_15_60_135_240(oracle):
     sum_ct = [S.add(a0, b0), S.add(a1, b1)]
     assert S.slot_decode(S.decrypt(sum_ct))[:4] == [8, 16, 24, 32]
     assert [int(v) for v in s0[:, 0]] == sum_ct[0][0]
+
+
+# ---------------------------------------------------------------------------------- RNS entry / exit (row a18)
+@pytest.mark.parametrize("n,bits,L", [(16, 30, 4), (16, 60, 4), (8, 120, 2), (32, 30, 8), (8, 250, 1)])
+def test_to_rns_and_crt_match_big_integers(oracle, n, bits, L):
+    moduli = nm.ntt_primes(bits, n, L)
+    Q = 1
+    for q in moduli:
+        Q *= q
+    rp = oracle.RnsPlan(n, moduli)
+    rng = random.Random(bits * L)
+    vals = [rng.randrange(Q) for _ in range(2 * n - 3)] + [0, Q - 1, 1]
+    V = oracle.to_limbs(vals).reshape(2, n, 4)
+    R = rp.to_rns(V)
+    for b in range(2):
+        for l, q in enumerate(moduli):
+            assert oracle.from_limbs(R[b, l]) == [v % q for v in vals[b * n:(b + 1) * n]]
+    assert oracle.from_limbs(rp.from_rns(R)) == vals
+    # to_rns accepts any 256-bit integer (values >= Q simply wrap mod each prime)
+    big = [rng.getrandbits(256) for _ in range(n)]
+    Rb = rp.to_rns(oracle.to_limbs(big).reshape(1, n, 4))
+    for l, q in enumerate(moduli):
+        assert oracle.from_limbs(Rb[0, l]) == [v % q for v in big]
+
+
+def test_crt_rejects_too_large_bases(oracle):
+    n = 8
+    rp = oracle.RnsPlan(n, nm.ntt_primes(60, n, 5))            # 300 bits
+    with pytest.raises(ValueError):
+        rp.from_rns(np.zeros((1, 5, n, 4), np.uint64))
