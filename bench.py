@@ -110,17 +110,18 @@ def main():
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("FHE_BENCH_FORCE_DIST") == "1"      # the latter: 1-rank RCCL smoke test
+    if use_dist:
         import torch                       # first, so the process has ONE libamdhip64 (same SONAME as ours)
     pkg = importlib.import_module("gpu-homomorphic-encryption_amd")
     sharding = importlib.import_module("gpu-homomorphic-encryption_amd.sharding")
-    if world > 1:
+    if use_dist:
         if args.device_override is not None:
             os.environ["LOCAL_RANK"] = str(args.device_override); local_rank = args.device_override
         dist = sharding.init_process_group(args.dist_backend)   # RCCL: barriers + max-over-ranks only, no payload collective
     if pkg.device_count() < 1:
         raise SystemExit("bench.py: no HIP device; the engine has no CPU fallback")
-    if world > 1:
+    if use_dist:
         rc = pkg.lib().fhe_hip_set_device(local_rank)
         assert rc == 0, pkg.lib().fhe_hip_last_error()
     red_dev = "cuda" if (dist is not None and args.dist_backend == "nccl") else "cpu"

@@ -24,7 +24,7 @@ def init_process_group(backend=None):
     """Rendezvous from the torchrun environment (MASTER_ADDR / MASTER_PORT / RANK / WORLD_SIZE)."""
     import torch.distributed as dist
     rank, world, local_rank = env_rank_world()
-    if world == 1:
+    if world == 1 and os.environ.get("FHE_BENCH_FORCE_DIST") != "1":
         return None
     if backend is None:
         import torch
