@@ -401,13 +401,15 @@ static int run256_transform(fhe_rns_ntt *h, fhe_dev::u256 *data, uint32_t polys,
         uint32_t chunk = polys - done < chunk_max ? polys - done : chunk_max;
         fhe_dev::u256 *d = data + (size_t)done * h->n;
         for (uint32_t s = 0; s < h->log_n;) {
-            uint32_t R = h->log_n - s >= 2 ? 2 : 1;   // radix-4 passes: radix-8 spills the 8 x 256-bit working set to scratch
+            uint32_t R = h->log_n - s >= 3 ? 3 : h->log_n - s;   // radix-8 passes (128 VGPRs, no scratch with the hand-scheduled product)
             dim3 grid(((h->n >> R) + 255) / 256, chunk), block(256);
             if (forward) {
-                if (R == 2) hipLaunchKernelGGL(fhe_dev::ntt256_fwd_pass<2>, grid, block, 0, h->stream, d, limbs, h->L, h->log_n, s);
+                if (R == 3) hipLaunchKernelGGL(fhe_dev::ntt256_fwd_pass<3>, grid, block, 0, h->stream, d, limbs, h->L, h->log_n, s);
+                else if (R == 2) hipLaunchKernelGGL(fhe_dev::ntt256_fwd_pass<2>, grid, block, 0, h->stream, d, limbs, h->L, h->log_n, s);
                 else hipLaunchKernelGGL(fhe_dev::ntt256_fwd_pass<1>, grid, block, 0, h->stream, d, limbs, h->L, h->log_n, s);
             } else {
-                if (R == 2) hipLaunchKernelGGL(fhe_dev::ntt256_inv_pass<2>, grid, block, 0, h->stream, d, limbs, h->L, h->log_n, s);
+                if (R == 3) hipLaunchKernelGGL(fhe_dev::ntt256_inv_pass<3>, grid, block, 0, h->stream, d, limbs, h->L, h->log_n, s);
+                else if (R == 2) hipLaunchKernelGGL(fhe_dev::ntt256_inv_pass<2>, grid, block, 0, h->stream, d, limbs, h->L, h->log_n, s);
                 else hipLaunchKernelGGL(fhe_dev::ntt256_inv_pass<1>, grid, block, 0, h->stream, d, limbs, h->L, h->log_n, s);
             }
             s += R;

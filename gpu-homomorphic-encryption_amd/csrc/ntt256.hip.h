@@ -6,9 +6,10 @@
 // include/bigint.cuh:27-140, include/ntt.cuh:147-167) with Montgomery-form twiddles, so data stays in
 // plain form exactly as in the reference.
 //
-// Roofline note: one 256-bit Montgomery product is ~136 v_mad_u64_u32; at ~14 integer MADs per byte of
-// compulsory traffic this path is bound by the integer multiplier, not by HBM, so it runs as plain
-// multi-pass radix-2^R register kernels over global memory (R <= 2 stages per launch, every access a
+// Roofline note: one 256-bit Montgomery product is 128 v_mad_u64_u32 + 128 v_addc_co_u32 (hand-scheduled
+// mont_mul_fips, u256_dev.h); at ~14 integer MADs per byte of compulsory traffic this path is bound by
+// integer issue, not by HBM, so it runs as plain
+// multi-pass radix-2^R register kernels over global memory (R <= 3 stages per launch, every access a
 // whole 32-byte container, consecutive lanes on consecutive containers) without LDS staging.
 #pragma once
 #include "u256_dev.h"
@@ -51,7 +52,7 @@ ntt256_fwd_pass(u256 *__restrict__ data, const Limb256 *__restrict__ limbs, uint
             const int k = ((hh >> pos) << (pos + 1)) | (hh & ((1 << pos) - 1));
             const uint32_t i = i0 + ((uint32_t)k << b_last);
             const u256 w = load_u256(P.tw_m + m + (i >> (b + 1)));
-            ct_butterfly(x[k], x[k | (1 << pos)], w, q, inv0);
+            ct_butterfly_fast(x[k], x[k | (1 << pos)], w, q, (uint32_t)inv0);
         }
     }
 #pragma unroll
@@ -82,13 +83,13 @@ ntt256_inv_pass(u256 *__restrict__ data, const Limb256 *__restrict__ limbs, uint
             const int k = ((hh >> j) << (j + 1)) | (hh & ((1 << j) - 1));
             const uint32_t i = i0 + ((uint32_t)k << b0);
             const u256 w = load_u256(P.itw_m + m + (i >> (b + 1)));
-            gs_butterfly(x[k], x[k | (1 << j)], w, q, inv0);
+            gs_butterfly_fast(x[k], x[k | (1 << j)], w, q, (uint32_t)inv0);
         }
     }
     if (b0 + R == log_n) {
         const u256 ninv = P.ninv_m;
 #pragma unroll
-        for (int k = 0; k < (1 << R); k++) x[k] = mont_mul(x[k], ninv, q, inv0);
+        for (int k = 0; k < (1 << R); k++) x[k] = mont_mul_fips(x[k], ninv, q, (uint32_t)inv0);
     }
 #pragma unroll
     for (int k = 0; k < (1 << R); k++) store_u256(poly + i0 + ((uint32_t)k << b0), x[k]);
@@ -104,7 +105,7 @@ ew256_rns_kernel(u256 *__restrict__ r, const u256 *__restrict__ a, const u256 *_
     for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < count; g += stride) {
         const Limb256 &P = limbs[(uint32_t)((g >> log_n) % L)];
         u256 x = load_u256(a + g), y = load_u256(b + g), o;
-        if (OP == 0) o = mont_mul(mont_mul(x, y, P.q, P.inv0), P.r2, P.q, P.inv0);
+        if (OP == 0) o = mont_mul_fips(mont_mul_fips(x, y, P.q, (uint32_t)P.inv0), P.r2, P.q, (uint32_t)P.inv0);
         else if (OP == 1) o = add_mod(x, y, P.q);
         else o = sub_mod(x, y, P.q);
         store_u256(r + g, o);
@@ -191,9 +192,10 @@ relin_mac256_kernel(u256 *__restrict__ acc0, u256 *__restrict__ acc1, const u256
         u256 s0, s1;
         s0.l[0] = s0.l[1] = s0.l[2] = s0.l[3] = 0; s1 = s0;
         for (uint32_t jk = 0; jk < LK; jk++) {
-            const u256 d = mont_mul(load_u256(D + (size_t)jk * per_digit + g), P.r2, P.q, P.inv0);      // d * R
-            s0 = add_mod(s0, mont_mul(d, load_u256(KB + (size_t)jk * per_ct + kidx), P.q, P.inv0), P.q);
-            s1 = add_mod(s1, mont_mul(d, load_u256(KA + (size_t)jk * per_ct + kidx), P.q, P.inv0), P.q);
+            const uint32_t qi = (uint32_t)P.inv0;
+            const u256 d = mont_mul_fips(load_u256(D + (size_t)jk * per_digit + g), P.r2, P.q, qi);      // d * R
+            s0 = add_mod(s0, mont_mul_fips(d, load_u256(KB + (size_t)jk * per_ct + kidx), P.q, qi), P.q);
+            s1 = add_mod(s1, mont_mul_fips(d, load_u256(KA + (size_t)jk * per_ct + kidx), P.q, qi), P.q);
         }
         store_u256(acc0 + g, s0);
         store_u256(acc1 + g, s1);

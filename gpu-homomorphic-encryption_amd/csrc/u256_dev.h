@@ -102,6 +102,96 @@ __device__ __forceinline__ u256 mont_mul(const u256 &a, const u256 &b, const u25
     return r;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Hand-scheduled Montgomery product for the NTT passes (odd q, exact inv0): finely integrated product scanning over
+// eight 32-bit words.  Every 32x32 product is one v_mad_u64_u32 into a 64-bit column accumulator whose carry-out goes
+// to its own SGPR pair and is folded into a third accumulator word by v_addc_co_u32.  On gfx950 a VALU read of an SGPR
+// (incl. VCC) written by the previous VALU instruction needs two wait states -- the compiler pads its own carry chains
+// with s_nop (156 of the 818 instructions of the compiled 64-bit-limb product).  Here three independent carries are in
+// flight at once (s[20:25]), so the multiplies themselves are the padding: 128 mads + 128 addc + 8 v_mul_lo_u32.
+// The value is the same canonical a*b*R^-1 mod q as mul_mod_montgomery (include/bigint.cuh:76-140) for a, b < q.
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void mac1(uint64_t &lo, uint32_t &hi, uint32_t a0, uint32_t b0) {
+    asm("v_mad_u64_u32 %0, s[20:21], %2, %3, %0\n\t"
+        "s_nop 1\n\t"
+        "v_addc_co_u32_e64 %1, s[20:21], 0, %1, s[20:21]"
+        : "+v"(lo), "+v"(hi) : "v"(a0), "v"(b0) : "s20", "s21");
+}
+__device__ __forceinline__ void mac2(uint64_t &lo, uint32_t &hi, uint32_t a0, uint32_t b0, uint32_t a1, uint32_t b1) {
+    asm("v_mad_u64_u32 %0, s[20:21], %2, %3, %0\n\t"
+        "v_mad_u64_u32 %0, s[22:23], %4, %5, %0\n\t"
+        "s_nop 0\n\t"
+        "v_addc_co_u32_e64 %1, s[20:21], 0, %1, s[20:21]\n\t"
+        "v_addc_co_u32_e64 %1, s[22:23], 0, %1, s[22:23]"
+        : "+v"(lo), "+v"(hi) : "v"(a0), "v"(b0), "v"(a1), "v"(b1) : "s20", "s21", "s22", "s23");
+}
+__device__ __forceinline__ void mac3(uint64_t &lo, uint32_t &hi, uint32_t a0, uint32_t b0, uint32_t a1, uint32_t b1, uint32_t a2, uint32_t b2) {
+    asm("v_mad_u64_u32 %0, s[20:21], %2, %3, %0\n\t"
+        "v_mad_u64_u32 %0, s[22:23], %4, %5, %0\n\t"
+        "v_mad_u64_u32 %0, s[24:25], %6, %7, %0\n\t"
+        "v_addc_co_u32_e64 %1, s[20:21], 0, %1, s[20:21]\n\t"
+        "v_addc_co_u32_e64 %1, s[22:23], 0, %1, s[22:23]\n\t"
+        "v_addc_co_u32_e64 %1, s[24:25], 0, %1, s[24:25]"
+        : "+v"(lo), "+v"(hi) : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2) : "s20", "s21", "s22", "s23", "s24", "s25");
+}
+
+struct w256 { uint32_t w[8]; };   // eight 32-bit words, little-endian (the same bytes as u256)
+__device__ __forceinline__ w256 to_words(const u256 &a) {
+    w256 r;
+#pragma unroll
+    for (int i = 0; i < 4; i++) { r.w[2 * i] = (uint32_t)a.l[i]; r.w[2 * i + 1] = (uint32_t)(a.l[i] >> 32); }
+    return r;
+}
+__device__ __forceinline__ u256 from_words(const w256 &a) {
+    u256 r;
+#pragma unroll
+    for (int i = 0; i < 4; i++) r.l[i] = (uint64_t)a.w[2 * i] | ((uint64_t)a.w[2 * i + 1] << 32);
+    return r;
+}
+
+// a, b < q (odd, < 2^255); qinv32 = -q^-1 mod 2^32 (= low word of MontgomeryParams::inv)
+__device__ __forceinline__ u256 mont_mul_fips(const u256 &a_, const u256 &b_, const u256 &q_, uint32_t qinv32) {
+    const w256 a = to_words(a_), b = to_words(b_), q = to_words(q_);
+    uint32_t m[8], t[8];
+    uint64_t lo = 0; uint32_t hi = 0;
+#pragma unroll
+    for (int k = 0; k < 15; k++) {
+        // operand list of column k: a_i*b_(k-i) for every valid i, m_i*q_(k-i) for every already known m_i
+        uint32_t xs[16], ys[16]; int cnt = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) { const int j = k - i; if (j >= 0 && j < 8) { xs[cnt] = a.w[i]; ys[cnt] = b.w[j]; cnt++; } }
+#pragma unroll
+        for (int i = 0; i < 8; i++) { const int j = k - i; if (j >= 0 && j < 8 && i < k && !(k < 8 && i == k)) { xs[cnt] = m[i]; ys[cnt] = q.w[j]; cnt++; } }
+        int c = 0;
+#pragma unroll
+        for (int g = 0; g < 6; g++) {
+            if (cnt - c >= 3) { mac3(lo, hi, xs[c], ys[c], xs[c + 1], ys[c + 1], xs[c + 2], ys[c + 2]); c += 3; }
+        }
+        if (cnt - c == 2) mac2(lo, hi, xs[c], ys[c], xs[c + 1], ys[c + 1]);
+        else if (cnt - c == 1) mac1(lo, hi, xs[c], ys[c]);
+        if (k < 8) {
+            m[k] = (uint32_t)lo * qinv32;
+            mac1(lo, hi, m[k], q.w[0]);            // clears the low word of the column
+        } else {
+            t[k - 8] = (uint32_t)lo;
+        }
+        lo = (lo >> 32) | ((uint64_t)hi << 32);
+        hi = 0;
+    }
+    t[7] = (uint32_t)lo;                             // bit 256 of the sum (lo >> 32) is zero for reduced operands
+    w256 tw; 
+#pragma unroll
+    for (int i = 0; i < 8; i++) tw.w[i] = t[i];
+    const u256 u = from_words(tw);
+    u256 d, r;
+    sub256(d, u, q_);
+    const bool underflow = d.l[3] > u.l[3];
+#pragma unroll
+    for (int i = 0; i < 4; i++) r.l[i] = underflow ? u.l[i] : d.l[i];
+    return r;
+}
+
 // include/ntt.cuh:147-155
 __device__ __forceinline__ void ct_butterfly(u256 &a, u256 &b, const u256 &w, const u256 &q, uint64_t inv0) {
     u256 t = mont_mul(b, w, q, inv0);
@@ -112,6 +202,18 @@ __device__ __forceinline__ void ct_butterfly(u256 &a, u256 &b, const u256 &w, co
 __device__ __forceinline__ void gs_butterfly(u256 &a, u256 &b, const u256 &w, const u256 &q, uint64_t inv0) {
     u256 s = add_mod(a, b, q);
     b = mont_mul(sub_mod(a, b, q), w, q, inv0);
+    a = s;
+}
+
+// the same butterflies on the hand-scheduled product (NTT passes; q odd prime, inv0 exact)
+__device__ __forceinline__ void ct_butterfly_fast(u256 &a, u256 &b, const u256 &w, const u256 &q, uint32_t qinv32) {
+    u256 t = mont_mul_fips(b, w, q, qinv32);
+    b = sub_mod(a, t, q);
+    a = add_mod(a, t, q);
+}
+__device__ __forceinline__ void gs_butterfly_fast(u256 &a, u256 &b, const u256 &w, const u256 &q, uint32_t qinv32) {
+    u256 s = add_mod(a, b, q);
+    b = mont_mul_fips(sub_mod(a, b, q), w, q, qinv32);
     a = s;
 }
 
