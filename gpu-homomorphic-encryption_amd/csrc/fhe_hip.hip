@@ -284,23 +284,20 @@ static int build_limbs52(fhe_rns_ntt *h, const std::vector<fhe_host::NttConstant
         const fhe_host::NttConstants &c = cs[l];
         const double q = (double)c.q.w[0];                 // q < 2^43: exact
         const uint64_t qi = c.q.w[0], n = h->n;
-        std::vector<double2> tw(n), itw(n);
-        for (uint32_t k = 0; k < n; k++) {
-            tw[k] = make_double2((double)c.tw[k].w[0], (double)c.tw[k].w[0] / q);      // companion = fl(w / q)
-            itw[k] = make_double2((double)c.itw[k].w[0], (double)c.itw[k].w[0] / q);
-        }
+        std::vector<double> tw(n), itw(n);                 // companions fl(w * fl(1/q)) are recomputed in the butterflies
+        for (uint32_t k = 0; k < n; k++) { tw[k] = (double)c.tw[k].w[0]; itw[k] = (double)c.itw[k].w[0]; }
         fhe_dev::Limb52 &P = limbs[l];
         std::memset(&P, 0, sizeof(P));
         auto mulq = [qi](uint64_t a, uint64_t b) { return (uint64_t)(((fhe_host::u128)a * b) % qi); };
         const uint64_t ninv = c.n_inv.w[0], nw = mulq(ninv, c.itw[1].w[0]);
-        P.q = q; P.q2 = 2 * q; P.qinv = 1.0 / q;
+        P.q = q; P.q2 = 1.0 / q; P.qinv = 1.0 / q;         // q2's slot carries fl(1/q): the skeleton hands it to the butterflies
         P.r1 = 1.0; P.r1_s = 1.0 / q;                       // no Montgomery factor on this path
         P.ninv = (double)ninv; P.ninv_s = (double)ninv / q;
         P.ninvw = (double)nw; P.ninvw_s = (double)nw / q;
         P.ninv_r = P.ninv; P.ninv_r_s = P.ninv_s; P.ninvw_r = P.ninvw; P.ninvw_r_s = P.ninvw_s;
         void *d = nullptr; int rc;
-        if ((rc = upload(h, tw, &d))) return rc; P.tw = (const double2 *)d;
-        if ((rc = upload(h, itw, &d))) return rc; P.itw = (const double2 *)d;
+        if ((rc = upload(h, tw, &d))) return rc; P.tw = (const double *)d;
+        if ((rc = upload(h, itw, &d))) return rc; P.itw = (const double *)d;
     }
     return upload(h, limbs, &h->d_limbs);
 }

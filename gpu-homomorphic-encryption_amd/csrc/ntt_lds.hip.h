@@ -65,6 +65,7 @@ struct IntField {
         x1 = Self::shoup_mul(X - Y + q2, ninvw, ninvw_s, q);
     }
     __device__ static __forceinline__ void regroup(E (&)[32], E, E) {}                       // integer ranges never grow
+    __device__ static __forceinline__ E regroup1(E x, E, E) { return x; }
     __device__ static __forceinline__ E canon_fwd(E x, E q, E q2, E) { return csub<E>(csub<E>(x, q2), q); }   // [0,4q) -> [0,q)
     __device__ static __forceinline__ E canon_inv(E x, E q) { return csub<E>(x, q); }       // [0,2q) -> [0,q)
     // NTT-domain product for the fused kernels: a canonical, b lazy (< 4q); result in (0,2q), carries 2^-W
@@ -132,7 +133,8 @@ struct F64 : IntField<F64, uint64_t, ulonglong2> {
 // values are brought back below 0.76 q once per 5-stage register group (regroup).
 struct F52 {
     using E = double;
-    using TW = double2;                 // (w, fl(w / q))
+    using TW = double;                  // w only: the companion fl(w / q) is recomputed as fl(w * fl(1/q)) (one FP64 multiply
+                                        // instead of 2 more VGPRs and 8 more L2 bytes per twiddle; |error| of c stays < 0.15)
     using V16 = v2u64;
     static constexpr int MAX_LOGN = 14;
     static constexpr int MULT_MINW = 2;
@@ -149,15 +151,18 @@ struct F52 {
         E c = __builtin_rint(x * qinv);
         return __builtin_fma(-c, q, x);
     }
-    __device__ static __forceinline__ void fwd_bfly(E &x0, E &x1, const TW &w, E q, E) {
-        E T = mulmod(x1, w.x, w.y, q);
+    // the skeleton passes q2 = 2q, which this field does not need: its slot carries fl(1/q) instead (Limb<F52>::q2)
+    __device__ static __forceinline__ void fwd_bfly(E &x0, E &x1, const TW &w, E q, E qinv) {
+#pragma clang fp contract(off)
+        E T = mulmod(x1, w, w * qinv, q);
         x1 = x0 - T;
         x0 = x0 + T;
     }
-    __device__ static __forceinline__ void inv_bfly(E &x0, E &x1, const TW &w, E q, E) {
+    __device__ static __forceinline__ void inv_bfly(E &x0, E &x1, const TW &w, E q, E qinv) {
+#pragma clang fp contract(off)
         E S = x0 + x1, D = x0 - x1;
         x0 = S;
-        x1 = mulmod(D, w.x, w.y, q);
+        x1 = mulmod(D, w, w * qinv, q);
     }
     __device__ static __forceinline__ void inv_last(E &x0, E &x1, E q, E, E ninv, E ninv_s, E ninvw, E ninvw_s) {
         E S = x0 + x1, D = x0 - x1;
@@ -168,6 +173,7 @@ struct F52 {
 #pragma unroll
         for (int r = 0; r < 32; r++) x[r] = reduce(x[r], q, qinv);
     }
+    __device__ static __forceinline__ E regroup1(E x, E q, E qinv) { return reduce(x, q, qinv); }
     __device__ static __forceinline__ E canon_fwd(E x, E q, E, E qinv) { E r = reduce(x, q, qinv); return r < 0 ? r + q : r; }
     __device__ static __forceinline__ E canon_inv(E x, E q) { return x < 0 ? x + q : x; }   // |x| < 0.76 q
     __device__ static __forceinline__ E pw_mul(E a, E b, E q, E qinv) {                     // a in [0,q), |b| < 2^48

@@ -1,15 +1,16 @@
 #!/bin/bash
 OUT=gpurun_out/matrix_40bit.jsonl; : > $OUT
-run() { echo "== $*" >&2; timeout -k 10 600 env $ENVV python bench.py --no-cpu-baseline "$@" | grep '^{' >> $OUT || echo "FAILED: $*" >&2; }
+run() { echo "== $ENVV $*" >&2; timeout -k 10 600 env $ENVV python bench.py --no-cpu-baseline "$@" | grep '^{' >> $OUT || echo "FAILED: $*" >&2; }
 ENVV="X=1"
 run --steps 10 --warmup 2 --op multiply --batch 1024 --bits 40 --limbs 3
-run --steps 10 --warmup 2 --op fwdinv   --batch 1024 --bits 40 --limbs 3
 run --steps 10 --warmup 2 --op multiply --batch 512 --n 16384 --limbs 6 --bits 40
+run --steps 10 --warmup 2 --op fwdinv   --batch 1024 --bits 40 --limbs 3
 run --steps 10 --warmup 2 --op ct       --batch 128 --n 16384 --limbs 6 --bits 40
 run --steps 10 --warmup 2 --op ct       --batch 512 --bits 40 --limbs 3
+run --steps 5 --warmup 1 --op ctrelin   --batch 128 --n 16384 --limbs 6 --bits 40
 ENVV="FHE_HIP_FORCE_WIDTH=64"
 run --steps 10 --warmup 2 --op multiply --batch 1024 --bits 40 --limbs 3
-run --steps 10 --warmup 2 --op multiply --batch 512 --n 16384 --limbs 6 --bits 40
+run --steps 10 --warmup 2 --op multiply --batch 1024 --bits 60 --limbs 2
 python - <<PY
 import json
 for l in open("$OUT"):
