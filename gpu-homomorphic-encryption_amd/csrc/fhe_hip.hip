@@ -221,10 +221,10 @@ static int build_limbs32(fhe_rns_ntt *h, const std::vector<fhe_host::NttConstant
     for (uint32_t l = 0; l < h->L; l++) {
         const fhe_host::NttConstants &c = cs[l];
         const uint64_t q = c.q.w[0], n = h->n;
-        std::vector<uint2> tw(n), itw(n);
+        std::vector<uint32_t> tw(n), itw(n);               // Montgomery form: w * 2^32 mod q
         for (uint32_t k = 0; k < n; k++) {
-            tw[k] = make_uint2((uint32_t)c.tw[k].w[0], shoup32(c.tw[k].w[0], q));
-            itw[k] = make_uint2((uint32_t)c.itw[k].w[0], shoup32(c.itw[k].w[0], q));
+            tw[k] = (uint32_t)((c.tw[k].w[0] << 32) % q);
+            itw[k] = (uint32_t)((c.itw[k].w[0] << 32) % q);
         }
         fhe_dev::Limb32 &P = limbs[l];
         std::memset(&P, 0, sizeof(P));
@@ -241,8 +241,8 @@ static int build_limbs32(fhe_rns_ntt *h, const std::vector<fhe_host::NttConstant
         P.ninv_r = (uint32_t)nr; P.ninv_r_s = shoup32(nr, q);
         P.ninvw_r = (uint32_t)nwr; P.ninvw_r_s = shoup32(nwr, q);
         void *d = nullptr; int rc;
-        if ((rc = upload(h, tw, &d))) return rc; P.tw = (const uint2 *)d;
-        if ((rc = upload(h, itw, &d))) return rc; P.itw = (const uint2 *)d;
+        if ((rc = upload(h, tw, &d))) return rc; P.tw = (const uint32_t *)d;
+        if ((rc = upload(h, itw, &d))) return rc; P.itw = (const uint32_t *)d;
     }
     return upload(h, limbs, &h->d_limbs);
 }
@@ -290,7 +290,7 @@ static int build_limbs52(fhe_rns_ntt *h, const std::vector<fhe_host::NttConstant
         std::memset(&P, 0, sizeof(P));
         auto mulq = [qi](uint64_t a, uint64_t b) { return (uint64_t)(((fhe_host::u128)a * b) % qi); };
         const uint64_t ninv = c.n_inv.w[0], nw = mulq(ninv, c.itw[1].w[0]);
-        P.q = q; P.q2 = 1.0 / q; P.qinv = 1.0 / q;         // q2's slot carries fl(1/q): the skeleton hands it to the butterflies
+        P.q = q; P.q2 = 2 * q; P.qinv = 1.0 / q;
         P.r1 = 1.0; P.r1_s = 1.0 / q;                       // no Montgomery factor on this path
         P.ninv = (double)ninv; P.ninv_s = (double)ninv / q;
         P.ninvw = (double)nw; P.ninvw_s = (double)nw / q;
