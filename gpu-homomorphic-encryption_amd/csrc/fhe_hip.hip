@@ -472,7 +472,8 @@ static int do_ew(fhe_rns_ntt *h, void *r, const void *a, const void *b, uint32_t
 }
 static int do_multiply(fhe_rns_ntt *h, void *d_r, const void *d_a, const void *d_b, uint32_t batch) {
     const uint32_t polys = batch * h->L;
-    if (d_r == d_a || d_r == d_b) return fail(FHE_ERR_INVALID_ARG, "multiply: result must not alias an operand");
+    // d_r may alias d_a and/or d_b, as in the reference (which copies its operands first, src/ntt.cu:50-58): every
+    // workgroup loads both of its operand polynomials completely before its first store, and the general path works on copies.
     if (h->width != FHE_WIDTH_256)
         return lds_run(h, fhe_dev::LDS_MULTIPLY, d_r, nullptr, nullptr, d_a, nullptr, d_b, nullptr, polys, "ntt_multiply_kernel");
     // general path: copies keep the operands intact (src/ntt.cu:50-58), one batched forward over both

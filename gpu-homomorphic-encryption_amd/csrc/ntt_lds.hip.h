@@ -443,7 +443,7 @@ ntt_inverse_kernel(char *__restrict__ data, const Limb<F> *__restrict__ limbs, u
 // NTTEngine::multiply in one launch: r = INTT(NTT(a) .* NTT(b)); HBM traffic = read a + read b + write r.
 template <class F, int LOGN, int MINW = 1>
 __global__ void __launch_bounds__(NttCfg<LOGN>::T, MINW)
-ntt_multiply_kernel(char *__restrict__ res, const char *__restrict__ a, const char *__restrict__ b,
+ntt_multiply_kernel(char *res, const char *a, const char *b,      // no __restrict__: res may alias a and / or b (in-place product)
                     const Limb<F> *__restrict__ limbs, uint32_t L) {
     using C = NttCfg<LOGN>;
     using E = typename F::E;

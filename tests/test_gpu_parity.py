@@ -260,7 +260,7 @@ def test_error_reporting(eng):
     e = eng.RnsNttEngine(2048, [40961])
     buf = eng.DeviceBuffer(2048 * 32)
     with pytest.raises(eng.FheError):
-        e.multiply(buf, buf, buf, 1)               # aliasing
+        e.ct_multiply(buf, buf, buf, buf, buf, buf, buf, 1)   # aliased tensor-product buffers
     with pytest.raises(eng.FheError):
         e.forward(buf, 0)                          # empty batch
 
@@ -502,3 +502,19 @@ def test_from_rns_rejects_oversized_basis(eng):
         e.from_rns(out, buf, 1)
     assert ei.value.code == -5
     e.to_rns(buf, out, 1)          # to_rns has no such limit
+
+
+@pytest.mark.parametrize("n,bits,L", [(8192, 30, 2), (4096, 40, 2), (2048, 60, 1), (256, 250, 1)])
+def test_in_place_multiply_and_squaring(eng, oracle, n, bits, L):
+    """Like the reference (which copies its operands, src/ntt.cu:50-58) the result may alias an operand."""
+    moduli = nm.ntt_primes(bits, n, L)
+    e = eng.RnsNttEngine(n, moduli); rp = oracle.RnsPlan(n, moduli)
+    a = rns_poly(97, moduli, n, 3); b = rns_poly(98, moduli, n, 3)
+    want = rp.polymul(a, b, threads=8); sq = rp.polymul(a, a, threads=8)
+    dA, dB = _up(eng, a), _up(eng, b)
+    e.multiply(dA, dA, dB, 3)                       # r aliases a
+    assert np.array_equal(dA.download(a.shape), want) and np.array_equal(dB.download(a.shape), b)
+    dA = _up(eng, a); e.multiply(dB, dA, dB, 3)     # r aliases b
+    assert np.array_equal(dB.download(a.shape), want)
+    dA = _up(eng, a); e.multiply(dA, dA, dA, 3)     # in-place square
+    assert np.array_equal(dA.download(a.shape), sq)
