@@ -1,13 +1,12 @@
 #!/bin/bash
 OUT=gpurun_out/matrix_relin.jsonl; : > $OUT
-run() { echo "== $*" >&2; timeout -k 10 600 env $ENVV python bench.py --no-cpu-baseline "$@" | grep '^{' >> $OUT || echo "FAILED: $*" >&2; }
-ENVV="X=1"
+run() { echo "== $ENVV $*" >&2; timeout -k 10 600 env $ENVV python bench.py --no-cpu-baseline "$@" | grep '^{' >> $OUT || echo "FAILED: $*" >&2; }
+for ENVV in "X=1" "FHE_HIP_KS16=1"; do
 run --steps 10 --warmup 2 --op relin   --batch 1024
 run --steps 10 --warmup 2 --op ctrelin --batch 1024
 run --steps 10 --warmup 2 --op relin   --batch 1024 --decomp-bits 30
 run --steps 10 --warmup 2 --op relin   --batch 256 --n 16384 --limbs 6
-ENVV="FHE_HIP_NO_FUSED_KEYSWITCH=1"
-run --steps 5 --warmup 1 --op relin   --batch 256
+done
 python - <<PY
 import json
 for l in open("$OUT"):
