@@ -115,6 +115,7 @@ def main():
         import torch                       # first, so the process has ONE libamdhip64 (same SONAME as ours)
     pkg = importlib.import_module("gpu-homomorphic-encryption_amd")
     sharding = importlib.import_module("gpu-homomorphic-encryption_amd.sharding")
+    pkg.build_library()                    # no-op when lib/libfhe_hip.so is up to date (it travels with the snapshot); file-locked
     if use_dist:
         if args.device_override is not None:
             os.environ["LOCAL_RANK"] = str(args.device_override); local_rank = args.device_override

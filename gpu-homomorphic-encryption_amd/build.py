@@ -1,4 +1,5 @@
 """Builds lib/libfhe_hip.so with hipcc for gfx950 (cross-compiles without a GPU)."""
+import fcntl
 import os
 import subprocess
 
@@ -20,15 +21,24 @@ def _sources():
 def build_library(force=False, jobs=None, verbose=False):
     """make -C csrc.  Skips the build when the library is newer than every source (the GPU box has
     the prebuilt .so from the snapshot and need not rebuild)."""
-    if not force and os.path.exists(_LIB):
-        newest = max(os.path.getmtime(s) for s in _sources())
-        if os.path.getmtime(_LIB) >= newest:
-            return _LIB
-    jobs = jobs or min(8, os.cpu_count() or 1)
-    cmd = ["make", "-C", _CSRC, f"-j{jobs}"]
-    if force:
-        cmd.append("-B")
-    res = subprocess.run(cmd, capture_output=not verbose, text=True)
-    if res.returncode != 0:
-        raise RuntimeError("libfhe_hip.so build failed:\n" + (res.stdout or "") + (res.stderr or ""))
+    def fresh():
+        return os.path.exists(_LIB) and os.path.getmtime(_LIB) >= max(os.path.getmtime(s) for s in _sources())
+
+    if not force and fresh():
+        return _LIB
+    os.makedirs(os.path.dirname(_LIB), exist_ok=True)
+    with open(os.path.join(os.path.dirname(_LIB), ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)       # ranks of one job (or parallel test workers) build once, the others wait
+        try:
+            if not force and fresh():
+                return _LIB
+            jobs = jobs or min(8, os.cpu_count() or 1)
+            cmd = ["make", "-C", _CSRC, f"-j{jobs}"]
+            if force:
+                cmd.append("-B")
+            res = subprocess.run(cmd, capture_output=not verbose, text=True)
+            if res.returncode != 0:
+                raise RuntimeError("libfhe_hip.so build failed:\n" + (res.stdout or "") + (res.stderr or ""))
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return _LIB

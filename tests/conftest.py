@@ -17,8 +17,11 @@ def pytest_configure(config):
 
 @pytest.fixture(scope="session")
 def pkg():
-    """The product package (hyphenated directory name, so imported by string)."""
-    return importlib.import_module(PKG_NAME)
+    """The product package (hyphenated directory name, so imported by string).  The C-ABI library is built on demand
+    (a no-op when lib/libfhe_hip.so is newer than its sources, e.g. when it travelled with the snapshot)."""
+    mod = importlib.import_module(PKG_NAME)
+    mod.build_library()
+    return mod
 
 
 @pytest.fixture(scope="session")
