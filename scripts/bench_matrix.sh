@@ -5,21 +5,30 @@ TAG=${1:-r01}
 OUT=gpurun_out/matrix_$TAG.jsonl
 : > $OUT
 run() { echo "== $*" >&2; timeout -k 10 600 python bench.py --no-cpu-baseline "$@" | grep '^{' >> $OUT || echo "FAILED: $*" >&2; }
+# configs[1]: fused polymul, N = 8192, 4 x 30-bit limbs -- batch sweep
 run --steps 10 --warmup 2 --op multiply --batch 4096
 run --steps 10 --warmup 2 --op multiply --batch 1024
 run --steps 20 --warmup 3 --op multiply --batch 64
 run --steps 50 --warmup 5 --op multiply --batch 1
 run --steps 10 --warmup 2 --op fwdinv   --batch 4096
+# configs[2]: ciphertext multiply (tensor product, relinearisation, both), N = 8192, log_q = 120
 run --steps 10 --warmup 2 --op ct       --batch 1024
-run --steps 10 --warmup 2 --op ct       --batch 128 --n 16384 --limbs 6 --bits 40
+run --steps 10 --warmup 2 --op relin    --batch 1024
+run --steps 10 --warmup 2 --op ctrelin  --batch 1024
+# configs[3] shape on one GPU: N = 16384, 6 limbs (30-bit and 40-bit bases), 128 ciphertexts = 1024 / 8
 run --steps 10 --warmup 2 --op multiply --batch 1024 --n 16384 --limbs 6 --bits 30
-run --steps 10 --warmup 2 --op multiply --batch 1024 --bits 60 --limbs 2
+run --steps 10 --warmup 2 --op ctrelin  --batch 128 --n 16384 --limbs 6 --bits 30
+run --steps 10 --warmup 2 --op ct       --batch 128 --n 16384 --limbs 6 --bits 40
+run --steps 5  --warmup 1 --op ctrelin  --batch 128 --n 16384 --limbs 6 --bits 40
+# modulus-width variants of configs[1]/[2]
 run --steps 10 --warmup 2 --op multiply --batch 1024 --bits 40 --limbs 3
-run --steps 3  --warmup 1 --op multiply --batch 128 --bits 64 --limbs 2
-run --steps 3  --warmup 1 --op multiply --batch 64 --bits 64 --limbs 4 --n 4096
+run --steps 10 --warmup 2 --op fwdinv   --batch 1024 --bits 40 --limbs 3
+run --steps 10 --warmup 2 --op multiply --batch 1024 --bits 60 --limbs 2
+run --steps 3  --warmup 1 --op multiply --batch 256 --bits 64 --limbs 2
+run --steps 3  --warmup 1 --op fwdinv   --batch 256 --bits 64 --limbs 2
 python - <<PY
 import json
 for l in open("$OUT"):
     d=json.loads(l); c=d["config"]; r=d["roofline"]
-    print(f'{c["op"]:9s} N={c["n"]:6d} L={c["limbs"]} bits={c["prime_bits"]:3d} B={c["batch_per_gpu"]:5d} {d["dtype"]:5s} {d["value"]:12.1f} {d["unit"]:10s} {d["ms_per_step"]:9.4f} ms  {r["achieved"]:8.1f} GB/s  frac {r["frac"]:.3f}')
+    print(f'{c["op"]:9s} N={c["n"]:6d} L={c["limbs"]} bits={c["prime_bits"]:3d} B={c["batch_per_gpu"]:5d} {d["dtype"][:5]:5s} {d["value"]:12.1f} {d["unit"]:10s} {d["ms_per_step"]:9.4f} ms  {r["achieved"]:8.1f} GB/s  frac {r["frac"]:.3f}')
 PY
