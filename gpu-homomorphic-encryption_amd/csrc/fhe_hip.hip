@@ -611,6 +611,25 @@ extern "C" int fhe_relin_keys_destroy(fhe_relin_keys_t *rk) {
     }
     return FHE_OK;
 }
+
+// packed key tables for the fused key-switch kernels (word-sized paths)
+template <class F>
+static int pack_relin_keys_t(fhe_rns_ntt *h, fhe_relin_keys *rk) {
+    const size_t elems = (size_t)rk->num_keys * h->L * h->n;
+    HIP_TRY(hipMalloc(&rk->d_pkb, elems * sizeof(typename F::E)));
+    HIP_TRY(hipMalloc(&rk->d_pka, elems * sizeof(typename F::E)));
+    hipLaunchKernelGGL((fhe_dev::pack_keys_kernel<F>), dim3(ew_grid(elems)), dim3(256), 0, h->stream, (typename F::E *)rk->d_pkb,
+                       (const typename F::V16 *)rk->d_kb, (const fhe_dev::Limb<F> *)h->d_limbs, h->L, h->log_n, rk->num_keys);
+    hipLaunchKernelGGL((fhe_dev::pack_keys_kernel<F>), dim3(ew_grid(elems)), dim3(256), 0, h->stream, (typename F::E *)rk->d_pka,
+                       (const typename F::V16 *)rk->d_ka, (const fhe_dev::Limb<F> *)h->d_limbs, h->L, h->log_n, rk->num_keys);
+    return post_launch(h->stream, "pack_keys_kernel");
+}
+static int pack_relin_keys(fhe_rns_ntt *h, fhe_relin_keys *rk) {
+    if (h->width == FHE_WIDTH_32) return pack_relin_keys_t<fhe_dev::F32>(h, rk);
+    if (h->width == FHE_WIDTH_52) return pack_relin_keys_t<fhe_dev::F52>(h, rk);
+    return pack_relin_keys_t<fhe_dev::F64>(h, rk);
+}
+
 extern "C" int fhe_relin_keys_create(fhe_rns_ntt_t *h, fhe_relin_keys_t **out, uint32_t decomp_bits,
                                      const void *const *d_keys_b, const void *const *d_keys_a, uint32_t num_keys) {
     if (!h || !out || !d_keys_b || !d_keys_a) return fail(FHE_ERR_INVALID_ARG, "relin_keys_create: null argument");
@@ -639,18 +658,7 @@ extern "C" int fhe_relin_keys_create(fhe_rns_ntt_t *h, fhe_relin_keys_t **out, u
     }
     int rc = do_forward(h, rk->d_kb, num_keys);
     if (!rc) rc = do_forward(h, rk->d_ka, num_keys);
-    if (!rc && h->width == FHE_WIDTH_32 && !getenv("FHE_HIP_NO_FUSED_KEYSWITCH")) {
-        using F = fhe_dev::F32;
-        const size_t elems = (size_t)num_keys * h->L * h->n;
-        if ((e = hipMalloc(&rk->d_pkb, elems * sizeof(F::E))) != hipSuccess || (e = hipMalloc(&rk->d_pka, elems * sizeof(F::E))) != hipSuccess) {
-            fhe_relin_keys_destroy(rk); return fail(FHE_ERR_HIP, std::string("relin_keys_create: ") + hipGetErrorString(e));
-        }
-        hipLaunchKernelGGL((fhe_dev::pack_keys_kernel<F>), dim3(ew_grid(elems)), dim3(256), 0, h->stream, (F::E *)rk->d_pkb, (const F::V16 *)rk->d_kb,
-                           (const fhe_dev::Limb<F> *)h->d_limbs, h->L, h->log_n, num_keys);
-        hipLaunchKernelGGL((fhe_dev::pack_keys_kernel<F>), dim3(ew_grid(elems)), dim3(256), 0, h->stream, (F::E *)rk->d_pka, (const F::V16 *)rk->d_ka,
-                           (const fhe_dev::Limb<F> *)h->d_limbs, h->L, h->log_n, num_keys);
-        rc = post_launch(h->stream, "pack_keys_kernel");
-    }
+    if (!rc && h->width != FHE_WIDTH_256 && !getenv("FHE_HIP_NO_FUSED_KEYSWITCH")) rc = pack_relin_keys(h, rk);
     if (rc) { fhe_relin_keys_destroy(rk); return rc; }
     *out = rk;
     return FHE_OK;
@@ -694,8 +702,8 @@ extern "C" int fhe_ct_relinearize(fhe_rns_ntt_t *h, const fhe_relin_keys_t *rk, 
     if (!rk || !d_c0 || !d_c1 || !d_c2) return fail(FHE_ERR_INVALID_ARG, "ct_relinearize: null argument");
     if (rk->owner != h) return fail(FHE_ERR_INVALID_ARG, "ct_relinearize: keys were imported for a different engine");
     if (d_c0 == d_c1 || d_c0 == d_c2 || d_c1 == d_c2) return fail(FHE_ERR_INVALID_ARG, "ct_relinearize: components must be distinct buffers");
-    if (rk->d_pkb) {   // 32-bit path: one fused launch
-        fhe_dev::lds_launch_fn fn = fhe_dev::lds_lookup(32, (int)h->log_n);
+    if (rk->d_pkb) {   // word-sized paths: one fused launch
+        fhe_dev::lds_launch_fn fn = fhe_dev::lds_lookup(h->width == FHE_WIDTH_32 ? 32 : h->width == FHE_WIDTH_52 ? 52 : 64, (int)h->log_n);
         if (!fn) return fail(FHE_ERR_UNSUPPORTED, "transform size outside the LDS-resident range");
         fhe_dev::LdsArgs A{fhe_dev::LDS_KEYSWITCH, d_c0, d_c1, nullptr, d_c2, nullptr, nullptr, nullptr, h->d_limbs, h->L, batch * h->L, h->stream};
         A.kb = rk->d_pkb; A.ka = rk->d_pka; A.K = rk->K; A.w = rk->decomp_bits;

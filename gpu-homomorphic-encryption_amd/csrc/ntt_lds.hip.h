@@ -678,7 +678,11 @@ pack_keys_kernel(typename F::E *__restrict__ packed, const typename F::V16 *__re
 // registers, transformed under q_i, multiplied with both key halves and accumulated in the NTT domain; two inverse
 // transforms and the additions to c0, c1 finish the job.  HBM traffic per ciphertext: L reads of c2 + read/write of c0, c1
 // = (L + 4) * S bytes (re-reads of c2 by the L workgroups of one ciphertext mostly hit the Infinity Cache).
-template <class F, int LOGN, int MINW = 1>
+// SPLIT = false: one workgroup per (ciphertext b, limb i) accumulates both key halves (4 live arrays per thread; 4-byte residues).
+// SPLIT = true : two workgroups per (b, i), one per key half (3 live arrays; 8-byte residues, whose four arrays would not fit the
+//                register file); the digit transforms are then computed twice, which is still far cheaper than the general
+//                composition's container-sized digit workspace.
+template <class F, int LOGN, int MINW = 1, bool SPLIT = false>
 __global__ void __launch_bounds__(NttCfg<LOGN>::T, MINW)
 ntt_keyswitch_kernel(char *__restrict__ c0, char *__restrict__ c1, const char *__restrict__ c2,
                      const typename F::E *__restrict__ kb, const typename F::E *__restrict__ ka,
@@ -688,56 +692,96 @@ ntt_keyswitch_kernel(char *__restrict__ c0, char *__restrict__ c1, const char *_
     constexpr int VPL = 16 / sizeof(E), NCH = 32 / VPL;
     typedef E VecE __attribute__((ext_vector_type(VPL)));
     __shared__ E lds[C::LDS_ELEMS];
-    // XCD-aware workgroup -> (ciphertext, limb) map: workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8
-    // names the L2 a workgroup shares), and the L limb-workgroups of one ciphertext all re-read the same c2, so they are
-    // given block indices that are congruent mod 8 and at most 8*L apart: the re-reads then hit one XCD's L2 instead of
-    // crossing the fabric L times.  Placement only changes speed, never results.
-    const uint32_t tid = threadIdx.x, bid = blockIdx.x, full = (gridDim.x / (8 * L)) * (8 * L);
-    uint32_t b, i;
-    if (bid < full) { const uint32_t s = bid >> 3; b = (bid & 7) + 8 * (s / L); i = s % L; }
-    else { b = bid / L; i = bid % L; }
+    // XCD-aware workgroup -> (ciphertext, limb[, half]) map: workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8
+    // names the L2 a workgroup shares), and the workgroups of one ciphertext all re-read the same c2, so they are given block
+    // indices that are congruent mod 8 and close together: the re-reads then hit one XCD's L2 instead of crossing the
+    // fabric.  Placement only changes speed, never results.
+    constexpr uint32_t H = SPLIT ? 2 : 1;
+    const uint32_t LH = L * H;
+    const uint32_t tid = threadIdx.x, bid = blockIdx.x, full = (gridDim.x / (8 * LH)) * (8 * LH);
+    uint32_t b, u;
+    if (bid < full) { const uint32_t s = bid >> 3; b = (bid & 7) + 8 * (s / LH); u = s % LH; }
+    else { b = bid / LH; u = bid % LH; }
+    const uint32_t i = u / H, half = u % H;
     const uint32_t p = b * L + i;
     const Limb<F> P = limbs[i];
-    E acc0[32], acc1[32], x[32], d[32];
+    if constexpr (!SPLIT) {
+        E acc0[32], acc1[32], x[32], d[32];
 #pragma unroll
-    for (int r = 0; r < 32; r++) { acc0[r] = 0; acc1[r] = 0; }
-    for (uint32_t j = 0; j < L; j++) {
-        load_A<F, LOGN>(c2 + ((size_t)b * L + j) * (C::N * 32), tid, x);
-        for (uint32_t k = 0; k < K; k++) {
+        for (int r = 0; r < 32; r++) { acc0[r] = 0; acc1[r] = 0; }
+        for (uint32_t j = 0; j < L; j++) {
+            load_A<F, LOGN>(c2 + ((size_t)b * L + j) * (C::N * 32), tid, x);
+            for (uint32_t k = 0; k < K; k++) {
 #pragma unroll
-            for (int r = 0; r < 32; r++) d[r] = F::digit(x[r], k * w, w);
-            fwd_core<F, LOGN>(d, lds, tid, P);
-            const size_t tbl = ((size_t)(j * K + k) * L + i) * C::N;
-            const VecE *pb = reinterpret_cast<const VecE *>(kb + tbl) + tid, *pa = reinterpret_cast<const VecE *>(ka + tbl) + tid;
+                for (int r = 0; r < 32; r++) d[r] = F::digit(x[r], k * w, w);
+                fwd_core<F, LOGN>(d, lds, tid, P);
+                const size_t tbl = ((size_t)(j * K + k) * L + i) * C::N;
+                const VecE *pb = reinterpret_cast<const VecE *>(kb + tbl) + tid, *pa = reinterpret_cast<const VecE *>(ka + tbl) + tid;
 #pragma unroll
-            for (int c = 0; c < NCH; c++) {
-                const VecE vb = pb[c * C::T], va = pa[c * C::T];
+                for (int c = 0; c < NCH; c++) {
+                    const VecE vb = pb[c * C::T], va = pa[c * C::T];
 #pragma unroll
-                for (int e = 0; e < VPL; e++) {
-                    const int r = c * VPL + e;
-                    acc0[r] = F::pw_add(acc0[r], F::pw_mul(vb[e], d[r], P.q, P.qinv), P.q, P.q2);
-                    acc1[r] = F::pw_add(acc1[r], F::pw_mul(va[e], d[r], P.q, P.qinv), P.q, P.q2);
+                    for (int e = 0; e < VPL; e++) {
+                        const int r = c * VPL + e;
+                        acc0[r] = F::pw_add(acc0[r], F::pw_mul(vb[e], d[r], P.q, P.qinv), P.q, P.q2);
+                        acc1[r] = F::pw_add(acc1[r], F::pw_mul(va[e], d[r], P.q, P.qinv), P.q, P.q2);
+                    }
                 }
+                __syncthreads();                      // every Z-pattern read is done before the next digit's exchange
             }
-            __syncthreads();                      // every Z-pattern read is done before the next digit's exchange
         }
+        // acc0 -> coefficient domain, + c0
+        inv_core<F, LOGN>(acc0, lds, tid, P, P.ninv, P.ninv_s, P.ninvw, P.ninvw_s);
+        load_A<F, LOGN>(c0 + (size_t)p * (C::N * 32), tid, x);
+#pragma unroll
+        for (int r = 0; r < 32; r++) acc0[r] = F::ew_add(F::canon_inv(acc0[r], P.q), x[r], P.q);
+        lds_put<PatA<LOGN>>(lds, tid, acc0);
+        __syncthreads();
+        store_from_lds<F, LOGN>(c0 + (size_t)p * (C::N * 32), lds, tid);
+        __syncthreads();
+        inv_core<F, LOGN>(acc1, lds, tid, P, P.ninv, P.ninv_s, P.ninvw, P.ninvw_s);
+        load_A<F, LOGN>(c1 + (size_t)p * (C::N * 32), tid, x);
+#pragma unroll
+        for (int r = 0; r < 32; r++) acc1[r] = F::ew_add(F::canon_inv(acc1[r], P.q), x[r], P.q);
+        lds_put<PatA<LOGN>>(lds, tid, acc1);
+        __syncthreads();
+        store_from_lds<F, LOGN>(c1 + (size_t)p * (C::N * 32), lds, tid);
+    } else {
+        const E *keys = half ? ka : kb;
+        char *dst = half ? c1 : c0;
+        E acc[32], d[32];
+#pragma unroll
+        for (int r = 0; r < 32; r++) acc[r] = 0;
+        for (uint32_t j = 0; j < L; j++) {
+            for (uint32_t k = 0; k < K; k++) {
+                // the c2 limb is re-read per digit (L2 / Infinity-Cache hits after the first) rather than held in 64 more VGPRs
+                load_A<F, LOGN>(c2 + ((size_t)b * L + j) * (C::N * 32), tid, d);
+#pragma unroll
+                for (int r = 0; r < 32; r++) d[r] = F::digit(d[r], k * w, w);
+                fwd_core<F, LOGN>(d, lds, tid, P);
+                __builtin_amdgcn_sched_barrier(0);   // keep the 16 key loads (64 VGPRs) from being hoisted into the transform
+                const VecE *pk = reinterpret_cast<const VecE *>(keys + ((size_t)(j * K + k) * L + i) * C::N) + tid;
+#pragma unroll
+                for (int c = 0; c < NCH; c++) {
+                    const VecE v = pk[c * C::T];
+#pragma unroll
+                    for (int e = 0; e < VPL; e++) {
+                        const int r = c * VPL + e;
+                        acc[r] = F::pw_add(acc[r], F::pw_mul(v[e], d[r], P.q, P.qinv), P.q, P.q2);
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        F::regroup(acc, P.q, P.qinv);              // floating-point sums of L*K products: back below q before the inverse
+        inv_core<F, LOGN>(acc, lds, tid, P, P.ninv, P.ninv_s, P.ninvw, P.ninvw_s);
+        load_A<F, LOGN>(dst + (size_t)p * (C::N * 32), tid, d);
+#pragma unroll
+        for (int r = 0; r < 32; r++) acc[r] = F::ew_add(F::canon_inv(acc[r], P.q), d[r], P.q);
+        lds_put<PatA<LOGN>>(lds, tid, acc);
+        __syncthreads();
+        store_from_lds<F, LOGN>(dst + (size_t)p * (C::N * 32), lds, tid);
     }
-    // acc0 -> coefficient domain, + c0
-    inv_core<F, LOGN>(acc0, lds, tid, P, P.ninv, P.ninv_s, P.ninvw, P.ninvw_s);
-    load_A<F, LOGN>(c0 + (size_t)p * (C::N * 32), tid, x);
-#pragma unroll
-    for (int r = 0; r < 32; r++) acc0[r] = F::ew_add(F::canon_inv(acc0[r], P.q), x[r], P.q);
-    lds_put<PatA<LOGN>>(lds, tid, acc0);
-    __syncthreads();
-    store_from_lds<F, LOGN>(c0 + (size_t)p * (C::N * 32), lds, tid);
-    __syncthreads();
-    inv_core<F, LOGN>(acc1, lds, tid, P, P.ninv, P.ninv_s, P.ninvw, P.ninvw_s);
-    load_A<F, LOGN>(c1 + (size_t)p * (C::N * 32), tid, x);
-#pragma unroll
-    for (int r = 0; r < 32; r++) acc1[r] = F::ew_add(F::canon_inv(acc1[r], P.q), x[r], P.q);
-    lds_put<PatA<LOGN>>(lds, tid, acc1);
-    __syncthreads();
-    store_from_lds<F, LOGN>(c1 + (size_t)p * (C::N * 32), lds, tid);
 }
 
 // ---- relinearisation building blocks (general path; the fused key-switch kernel for F32 is below) --------------------

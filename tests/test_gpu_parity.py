@@ -341,11 +341,12 @@ def test_relinearize_matches_oracle(eng, oracle, n, spec, w, batch):
         e.import_relin_keys(w, dkb[:-1], dka[:-1])
 
 
-def test_relinearize_general_path_on_32bit_moduli(eng, oracle, monkeypatch):
-    """The unfused composition (digit embedding, batched NTT, MAC) must agree with the fused key-switch kernel."""
+@pytest.mark.parametrize("bits", [30, 40, 60])
+def test_relinearize_general_path_on_word_sized_moduli(eng, oracle, monkeypatch, bits):
+    """The unfused composition (digit embedding, batched NTT, MAC) must agree with the fused key-switch kernels."""
     monkeypatch.setenv("FHE_HIP_NO_FUSED_KEYSWITCH", "1")
     n, w, batch = 4096, 16, 2
-    moduli = nm.ntt_primes(30, n, 3); L = 3
+    moduli = nm.ntt_primes(bits, n, 3); L = 3
     e = eng.RnsNttEngine(n, moduli); rp = oracle.RnsPlan(n, moduli)
     K = e.relin_num_digits(w)
     kb = _random_keys(moduli, n, L * K, 300); ka = _random_keys(moduli, n, L * K, 700)
