@@ -519,3 +519,19 @@ def test_in_place_multiply_and_squaring(eng, oracle, n, bits, L):
     assert np.array_equal(dB.download(a.shape), want)
     dA = _up(eng, a); e.multiply(dA, dA, dA, 3)     # in-place square
     assert np.array_equal(dA.download(a.shape), sq)
+
+
+@pytest.mark.parametrize("n,bits,L,batch", [(2048, 30, 2, 19), (2048, 30, 3, 40), (2048, 40, 2, 21), (2048, 60, 1, 17)])
+def test_relinearize_xcd_mapped_batches(eng, oracle, n, bits, L, batch):
+    """Batches large enough that the key-switch kernel's XCD-aware block -> (ciphertext, limb) map is in effect for most
+    workgroups and the identity map for the tail (batch not a multiple of 8)."""
+    moduli = nm.ntt_primes(bits, n, L); w = 16
+    e = eng.RnsNttEngine(n, moduli); rp = oracle.RnsPlan(n, moduli)
+    K = e.relin_num_digits(w)
+    kb = _random_keys(moduli, n, L * K, 1100); ka = _random_keys(moduli, n, L * K, 1900)
+    c0, c1, c2 = (rns_poly(s, moduli, n, batch) for s in (151, 152, 153))
+    rk = e.import_relin_keys(w, [_up(eng, k) for k in kb], [_up(eng, k) for k in ka])
+    d0, d1, d2 = _up(eng, c0), _up(eng, c1), _up(eng, c2)
+    e.relinearize(rk, d0, d1, d2, batch)
+    w0, w1 = rp.relinearize(w, c0, c1, c2, kb, ka, threads=8)
+    assert np.array_equal(d0.download(c0.shape), w0) and np.array_equal(d1.download(c0.shape), w1)
