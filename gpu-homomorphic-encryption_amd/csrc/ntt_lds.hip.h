@@ -111,14 +111,13 @@ struct F32Base : IntField<Self, uint32_t, TW_> {
     __device__ static __forceinline__ bool upper_nonzero(const V16 &v) { return (v.y | v.z | v.w) != 0; }
     __device__ static __forceinline__ bool any_nonzero(const V16 &v) { return (v.x | v.y | v.z | v.w) != 0; }
 };
-// Production 32-bit field: twiddles in Montgomery form w*2^32 mod q -- 4 multiply-class instructions per butterfly instead
+// 32-bit field: twiddles in Montgomery form w*2^32 mod q -- 4 multiply-class instructions per butterfly instead
 // of Shoup's 3, but 4 instead of 8 bytes per twiddle (registers, L2 traffic, vector-memory issue slots).  Interleaved A/B
-// on one MI355X (scratch/kbench.hip, batch 4096): 6.10 vs 6.02 TB/s on the fused multiply, bit-identical results.
+// against Shoup-form twiddles on one MI355X (scratch/kbench.hip, batch 4096): 6.10 vs 6.02 TB/s on the fused multiply,
+// bit-identical results.
 struct F32 : F32Base<F32, uint32_t> {
     template <class L> __device__ static __forceinline__ E tw_mul(E x, const uint32_t &w, const L &P) { return mont_mul(x, w, P.q, P.qinv); }
 };
-// Shoup-form twiddles (w, floor(w*2^32/q)), kept for the A/B in scratch/kbench.hip
-struct F32S : F32Base<F32S, uint2> {};
 struct F64 : IntField<F64, uint64_t, ulonglong2> {
     using V16 = v2u64;
     static constexpr int MAX_LOGN = 14; // 2^15 x 8 B does not fit the 160 KiB LDS
@@ -508,51 +507,6 @@ ntt_mac2_kernel(char *__restrict__ res, const char *__restrict__ a0, const char 
     lds_put<PatA<LOGN>>(lds, tid, acc);
     __syncthreads();
     store_from_lds<F, LOGN>(res + off, lds, tid);
-}
-
-// Persistent form of the fused multiply: gridDim.x workgroups stride over the polynomials and keep the NEXT
-// pair's HBM loads in flight (64 VGPRs) while the current pair is transformed, so a workgroup never sits idle
-// between its store phase and its next load phase, and there is no tail of partially filled dispatch rounds.
-template <class F, int LOGN, int MINW>
-__global__ void __launch_bounds__(NttCfg<LOGN>::T, MINW)
-ntt_multiply_persistent_kernel(char *__restrict__ res, const char *__restrict__ a, const char *__restrict__ b,
-                               const Limb<F> *__restrict__ limbs, uint32_t L, uint32_t polys) {
-    using C = NttCfg<LOGN>;
-    using E = typename F::E;
-    __shared__ E lds[C::LDS_ELEMS];
-    const uint32_t tid = threadIdx.x;
-    uint32_t p = blockIdx.x;
-    if (p >= polys) return;
-    E x[32], y[32], xn[32], yn[32];
-    load_A<F, LOGN>(a + (size_t)p * (C::N * 32), tid, x);
-    load_A<F, LOGN>(b + (size_t)p * (C::N * 32), tid, y);
-    for (;;) {
-        const uint32_t pn = p + gridDim.x;
-        const bool more = pn < polys;               // workgroup-uniform
-        if (more) {
-            load_A<F, LOGN>(a + (size_t)pn * (C::N * 32), tid, xn);
-            load_A<F, LOGN>(b + (size_t)pn * (C::N * 32), tid, yn);
-        }
-        const Limb<F> P = limbs[p % L];
-        fwd_core<F, LOGN>(x, lds, tid, P);
-#pragma unroll
-        for (int r = 0; r < 32; r++) x[r] = F::canon_fwd(x[r], P.q, P.q2, P.qinv);
-        __syncthreads();
-        fwd_core<F, LOGN>(y, lds, tid, P);
-#pragma unroll
-        for (int r = 0; r < 32; r++) x[r] = F::pw_mul(x[r], y[r], P.q, P.qinv);
-        inv_core<F, LOGN>(x, lds, tid, P, P.ninv_r, P.ninv_r_s, P.ninvw_r, P.ninvw_r_s);
-#pragma unroll
-        for (int r = 0; r < 32; r++) x[r] = F::canon_inv(x[r], P.q);
-        lds_put<PatA<LOGN>>(lds, tid, x);
-        __syncthreads();
-        store_from_lds<F, LOGN>(res + (size_t)p * (C::N * 32), lds, tid);
-        if (!more) break;
-        __syncthreads();                            // store_from_lds reads other threads' slots
-#pragma unroll
-        for (int r = 0; r < 32; r++) { x[r] = xn[r]; y[r] = yn[r]; }
-        p = pn;
-    }
 }
 
 // FHEContext::multiply tensor product in one launch (src/fhe.cu:199-218): 4 forward + 3 inverse transforms,

@@ -6,7 +6,7 @@
 #include <vector>
 #include <algorithm>
 #include "../gpu-homomorphic-encryption_amd/csrc/host_math.hpp"
-#include "../gpu-homomorphic-encryption_amd/csrc/ntt_lds.hip.h"
+#include "experiments/persistent_multiply.hip.h"
 using namespace fhe_dev;
 typedef Limb<F32S> LimbS;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1);} } while (0)
