@@ -658,7 +658,17 @@ extern "C" int fhe_relin_keys_create(fhe_rns_ntt_t *h, fhe_relin_keys_t **out, u
     }
     int rc = do_forward(h, rk->d_kb, num_keys);
     if (!rc) rc = do_forward(h, rk->d_ka, num_keys);
-    if (!rc && h->width != FHE_WIDTH_256 && !getenv("FHE_HIP_NO_FUSED_KEYSWITCH")) rc = pack_relin_keys(h, rk);
+    // The fused kernels feed a digit of limb j (< min(2^w, q_j)) straight into limb i's lazy forward transform, whose
+    // integer butterflies accept inputs below 4*q_i; bases mixing very different prime sizes go through the general
+    // composition, which reduces every digit modulo q_i first.
+    bool digits_fit = true;
+    if (h->width == FHE_WIDTH_32 || h->width == FHE_WIDTH_64) {
+        fhe_host::u128 q_min = ~(fhe_host::u128)0, q_max = 0;
+        for (const U256 &q : h->moduli) { fhe_host::u128 v = q.w[0]; q_min = v < q_min ? v : q_min; q_max = v > q_max ? v : q_max; }
+        fhe_host::u128 digit_bound = decomp_bits >= 64 ? q_max : (((fhe_host::u128)1 << decomp_bits) < q_max ? ((fhe_host::u128)1 << decomp_bits) : q_max);
+        digits_fit = digit_bound <= 4 * q_min;
+    }
+    if (!rc && h->width != FHE_WIDTH_256 && digits_fit && !getenv("FHE_HIP_NO_FUSED_KEYSWITCH")) rc = pack_relin_keys(h, rk);
     if (rc) { fhe_relin_keys_destroy(rk); return rc; }
     *out = rk;
     return FHE_OK;

@@ -535,3 +535,32 @@ def test_relinearize_xcd_mapped_batches(eng, oracle, n, bits, L, batch):
     e.relinearize(rk, d0, d1, d2, batch)
     w0, w1 = rp.relinearize(w, c0, c1, c2, kb, ka, threads=8)
     assert np.array_equal(d0.download(c0.shape), w0) and np.array_equal(d1.download(c0.shape), w1)
+
+
+def test_relinearize_mixed_prime_sizes(eng, oracle):
+    """A basis mixing 20-bit and 30-bit primes with w = 30: digits of the wide limbs exceed the lazy range of the narrow
+    limb, so the engine must take the general composition (which reduces each digit first)."""
+    n, w, batch = 2048, 30, 3
+    moduli = nm.ntt_primes(20, n, 1) + nm.ntt_primes(30, n, 2); L = 3
+    e = eng.RnsNttEngine(n, moduli); rp = oracle.RnsPlan(n, moduli)
+    assert e.width_class == 1
+    K = e.relin_num_digits(w)
+    kb = _random_keys(moduli, n, L * K, 2100); ka = _random_keys(moduli, n, L * K, 2900)
+    c0, c1, c2 = (rns_poly(s, moduli, n, batch) for s in (251, 252, 253))
+    top = c2.copy()
+    for l, q in enumerate(moduli):
+        top[:, l, :, 0] = q - 1                      # largest digits
+    rk = e.import_relin_keys(w, [_up(eng, k) for k in kb], [_up(eng, k) for k in ka])
+    for cc2 in (c2, top):
+        d0, d1, d2 = _up(eng, c0), _up(eng, c1), _up(eng, cc2)
+        e.relinearize(rk, d0, d1, d2, batch)
+        w0, w1 = rp.relinearize(w, c0, c1, cc2, kb, ka, threads=8)
+        assert np.array_equal(d0.download(c0.shape), w0) and np.array_equal(d1.download(c0.shape), w1)
+    # and with w = 16 the fused kernel is in range again
+    K = e.relin_num_digits(16)
+    kb = _random_keys(moduli, n, L * K, 3100); ka = _random_keys(moduli, n, L * K, 3900)
+    rk = e.import_relin_keys(16, [_up(eng, k) for k in kb], [_up(eng, k) for k in ka])
+    d0, d1, d2 = _up(eng, c0), _up(eng, c1), _up(eng, top)
+    e.relinearize(rk, d0, d1, d2, batch)
+    w0, w1 = rp.relinearize(16, c0, c1, top, kb, ka, threads=8)
+    assert np.array_equal(d0.download(c0.shape), w0) and np.array_equal(d1.download(c0.shape), w1)
