@@ -564,3 +564,49 @@ def test_relinearize_mixed_prime_sizes(eng, oracle):
     e.relinearize(rk, d0, d1, d2, batch)
     w0, w1 = rp.relinearize(16, c0, c1, top, kb, ka, threads=8)
     assert np.array_equal(d0.download(c0.shape), w0) and np.array_equal(d1.download(c0.shape), w1)
+
+
+def test_randomized_configurations(eng, oracle):
+    """Seeded sweep over (n, prime width, limbs, batch, operation) -- every width class, sizes on both sides of the LDS
+    range, odd batches -- each compared bit-exactly with the oracle."""
+    rng = random.Random(20260101)
+    widths = [20, 25, 29, 30, 31, 36, 40, 43, 44, 50, 58, 62, 63, 64, 90, 128, 200, 250]
+    for trial in range(28):
+        log_n = rng.choice([3, 5, 8, 10, 11, 11, 12, 12, 13, 13, 14])
+        n = 1 << log_n
+        bits = rng.choice(widths)
+        if bits < log_n + 3:
+            bits = log_n + 4
+        L = rng.choice([1, 1, 2, 3, 4, 5]) if bits < 100 else rng.choice([1, 2])
+        batch = rng.choice([1, 2, 3, 5, 7])
+        if n * L * batch * (4 if bits > 64 else 1) > 300000:
+            batch = 1
+        moduli = nm.ntt_primes(bits, n, L)
+        e = eng.RnsNttEngine(n, moduli); rp = oracle.RnsPlan(n, moduli)
+        a = rns_poly(1000 + trial, moduli, n, batch); b = rns_poly(2000 + trial, moduli, n, batch)
+        dA, dB, dR = _up(eng, a), _up(eng, b), eng.DeviceBuffer(a.nbytes)
+        tag = f"trial {trial}: n={n} bits={bits} L={L} batch={batch} width={e.width_class}"
+        op = trial % 4
+        if op == 0:
+            e.multiply(dR, dA, dB, batch)
+            assert np.array_equal(dR.download(a.shape), rp.polymul(a, b, threads=8)), tag
+        elif op == 1:
+            e.forward(dA, batch)
+            assert np.array_equal(dA.download(a.shape), rp.forward(a, threads=8)), tag
+            e.inverse(dA, batch)
+            assert np.array_equal(dA.download(a.shape), a), tag
+        elif op == 2:
+            c = [eng.DeviceBuffer(a.nbytes) for _ in range(3)]
+            e.ct_multiply(c[0], c[1], c[2], dA, dB, dB, dA, batch)
+            w = rp.ct_multiply(a, b, b, a, threads=8)
+            for got, want in zip(c, w):
+                assert np.array_equal(got.download(a.shape), want), tag
+        else:
+            wbits = rng.choice([8, 16, 30, 64])
+            K = e.relin_num_digits(wbits)
+            kb = _random_keys(moduli, n, L * K, 5000 + trial); ka = _random_keys(moduli, n, L * K, 6000 + trial)
+            rk = e.import_relin_keys(wbits, [_up(eng, k) for k in kb], [_up(eng, k) for k in ka])
+            c2 = rns_poly(3000 + trial, moduli, n, batch); d2 = _up(eng, c2)
+            e.relinearize(rk, dA, dB, d2, batch)
+            w0, w1 = rp.relinearize(wbits, a, b, c2, kb, ka, threads=8)
+            assert np.array_equal(dA.download(a.shape), w0) and np.array_equal(dB.download(a.shape), w1), tag + f" w={wbits}"
