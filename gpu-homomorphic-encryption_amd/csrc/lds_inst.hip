@@ -40,7 +40,7 @@ void CAT(lds_launch_, FHE_FIELD, FHE_LOGN)(const LdsArgs &A) {
             }
             break;
         case LDS_KEYSWITCH:
-            if constexpr (lds_keyswitch_split(sizeof(typename F::E))) {
+            if constexpr (lds_keyswitch_split(sizeof(typename F::E), LOGN)) {
                 hipLaunchKernelGGL((ntt_keyswitch_kernel<F, LOGN, 2, true>), dim3(A.polys * 2), block, 0, A.stream, (char *)A.r0, (char *)A.r1,
                                    (const char *)A.a0, (const typename F::E *)A.kb, (const typename F::E *)A.ka, limbs, A.L, A.K, A.w);
             } else {

@@ -10,9 +10,10 @@ enum LdsOp { LDS_FORWARD = 0, LDS_INVERSE = 1, LDS_MULTIPLY = 2, LDS_CT_MULTIPLY
 
 // true when the instance runs the tensor product as one fused launch; otherwise LDS_CT_MULTIPLY issues
 // multiply(c0), multiply(c2) and the two-product kernel for c1 (three launches, 11*S instead of 7*S bytes)
-constexpr bool lds_ct_fused(int elem_bytes, int log_n) { return elem_bytes == 4 || log_n <= 13; }
-// key switching: 4-byte residues run one workgroup per (ciphertext, limb); 8-byte residues two (one per key half)
-constexpr bool lds_keyswitch_split(int elem_bytes) { return elem_bytes == 8; }
+constexpr bool lds_ct_fused(int elem_bytes, int log_n) { return elem_bytes == 4 ? log_n <= 14 : log_n <= 13; }   // 1024-thread blocks cap a thread at 128 VGPRs
+// key switching: 4-byte residues run one workgroup per (ciphertext, limb); 8-byte residues and 1024-thread blocks (N = 2^15)
+// two, one per key half (three live arrays instead of four)
+constexpr bool lds_keyswitch_split(int elem_bytes, int log_n) { return elem_bytes == 8 || log_n >= 15; }
 
 struct LdsArgs {
     int op;

@@ -610,3 +610,23 @@ def test_randomized_configurations(eng, oracle):
             e.relinearize(rk, dA, dB, d2, batch)
             w0, w1 = rp.relinearize(wbits, a, b, c2, kb, ka, threads=8)
             assert np.array_equal(dA.download(a.shape), w0) and np.array_equal(dB.download(a.shape), w1), tag + f" w={wbits}"
+
+
+def test_largest_lds_size_tensor_and_keyswitch(eng, oracle):
+    """N = 2^15 (1024-thread workgroups): the tensor product runs as three launches and key switching in its split form."""
+    n, L, w = 32768, 2, 16
+    moduli = nm.ntt_primes(30, n, L)
+    e = eng.RnsNttEngine(n, moduli); rp = oracle.RnsPlan(n, moduli)
+    a0, a1, b0, b1 = (rns_poly(s, moduli, n, 1) for s in (301, 302, 303, 304))
+    d = [_up(eng, x) for x in (a0, a1, b0, b1)]
+    c = [eng.DeviceBuffer(a0.nbytes) for _ in range(3)]
+    e.ct_multiply(c[0], c[1], c[2], d[0], d[1], d[2], d[3], 1)
+    w0, w1, w2 = rp.ct_multiply(a0, a1, b0, b1, threads=8)
+    for got, want in zip(c, (w0, w1, w2)):
+        assert np.array_equal(got.download(a0.shape), want)
+    K = e.relin_num_digits(w)
+    kb = _random_keys(moduli, n, L * K, 4100); ka = _random_keys(moduli, n, L * K, 4900)
+    rk = e.import_relin_keys(w, [_up(eng, k) for k in kb], [_up(eng, k) for k in ka])
+    e.relinearize(rk, c[0], c[1], c[2], 1)
+    r0, r1 = rp.relinearize(w, w0, w1, w2, kb, ka, threads=8)
+    assert np.array_equal(c[0].download(a0.shape), r0) and np.array_equal(c[1].download(a0.shape), r1)
