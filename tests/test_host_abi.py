@@ -117,3 +117,11 @@ def test_oracle_reproduces_golden_digests(oracle, golden_dir):
         assert hashlib.sha256(fa.tobytes()).hexdigest() == c["forward_sha256"]
         assert [int(v) for v in fa[0, 0, :8, 0]] == c["forward_first8"]
         assert hashlib.sha256(rp.polymul(a, b, threads=4).tobytes()).hexdigest() == c["polymul_sha256"]
+
+
+def test_header_is_plain_c():
+    """The boundary is a C ABI: include/fhe_hip.h must compile as C99 on its own."""
+    import subprocess
+    res = subprocess.run(["gcc", "-x", "c", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-fsyntax-only",
+                          os.path.join(ROOT, "include", "fhe_hip.h")], capture_output=True, text=True)
+    assert res.returncode == 0 and not res.stderr.strip(), res.stderr
