@@ -64,7 +64,7 @@ int fhe_hip_device_count(int *count);
 int fhe_hip_set_device(int device);
 int fhe_hip_get_device(int *device);
 int fhe_hip_device_name(char *buf, size_t buflen);            /* gcnArchName + marketing name */
-int fhe_hip_malloc(void **d_ptr, size_t bytes);               /* cudaMalloc   (src/polynomial.cpp analogue: src/polynomial.cu:8) */
+int fhe_hip_malloc(void **d_ptr, size_t bytes);               /* cudaMalloc   (src/polynomial.cu:8) */
 int fhe_hip_free(void *d_ptr);                                /* cudaFree     (src/polynomial.cu:13) */
 int fhe_hip_memset(void *d_ptr, int value, size_t bytes);     /* cudaMemset   (src/polynomial.cu:9) */
 int fhe_hip_memcpy_h2d(void *d_dst, const void *h_src, size_t bytes);
