@@ -75,6 +75,7 @@ def lib():
         "fhe_rns_check_canonical": ([vp, vp, u32], ci),
         "fhe_rns_to_rns": ([vp, vp, vp, u32], ci),
         "fhe_rns_from_rns": ([vp, vp, vp, u32], ci),
+        "fhe_rns_rescale_drop_last": ([vp, vp, vp, u32], ci),
         "fhe_relin_num_digits": ([vp, u32, P(u32)], ci),
         "fhe_relin_keys_create": ([vp, P(vp), u32, P(vp), P(vp), u32], ci),
         "fhe_relin_keys_destroy": ([vp], ci),
@@ -287,6 +288,9 @@ class RnsNttEngine:
 
     def from_rns(self, d_values, d_rns, batch=1):
         _check(lib().fhe_rns_from_rns(self.h, _ptr(d_values), _ptr(d_rns), batch))
+
+    def rescale_drop_last(self, d_out, d_in, batch=1):
+        _check(lib().fhe_rns_rescale_drop_last(self.h, _ptr(d_out), _ptr(d_in), batch))
 
     def relin_num_digits(self, decomp_bits):
         k = ctypes.c_uint32(0); _check(lib().fhe_relin_num_digits(self.h, decomp_bits, ctypes.byref(k))); return k.value

@@ -189,6 +189,7 @@ struct fhe_rns_ntt {
     uint32_t *d_flag = nullptr;
     std::vector<U256> moduli;
     void *d_crt = nullptr;               // CrtLimb[L], built on first use of to_rns / from_rns (owned by d_tables)
+    void *d_rescale = nullptr;           // RescaleLimb[L-1], built on first use of rescale_drop_last (owned by d_tables)
     fhe_dev::CrtBig crt_big;
     int crt_state = 0;                   // 0 = not built, 1 = ready, -1 = Q too large for from_rns (to_rns still fine)
 };
@@ -807,6 +808,29 @@ extern "C" int fhe_rns_from_rns(fhe_rns_ntt_t *h, void *d_values, const void *d_
     hipLaunchKernelGGL(fhe_dev::from_rns_kernel, dim3(ew_grid(count)), dim3(256), 0, h->stream, (fhe_dev::u256 *)d_values, (const fhe_dev::u256 *)d_rns,
                        (const fhe_dev::CrtLimb *)h->d_crt, h->crt_big, h->L, h->log_n, count);
     return post_launch(h->stream, "from_rns_kernel");
+}
+
+
+extern "C" int fhe_rns_rescale_drop_last(fhe_rns_ntt_t *h, void *d_out, const void *d_in, uint32_t batch) {
+    int rc = check_call(h, batch, "rescale_drop_last"); if (rc) return rc;
+    if (!d_out || !d_in || d_out == d_in) return fail(FHE_ERR_INVALID_ARG, "rescale_drop_last: null or aliased argument");
+    if (h->L < 2) return fail(FHE_ERR_INVALID_ARG, "rescale_drop_last: needs at least two primes");
+    if ((rc = ensure_crt(h))) return rc;
+    if (!h->d_rescale) {
+        std::vector<fhe_dev::RescaleLimb> rs(h->L - 1);
+        const U256 &ql = h->moduli[h->L - 1];
+        for (uint32_t l = 0; l + 1 < h->L; l++) {
+            fhe_host::Mod M(h->moduli[l]);
+            U256 qm2; fhe_host::sub_to(qm2, M.q, U256(2));
+            U256 inv_m = M.pow_m(M.to_mont(M.reduce(ql)), qm2);                    // (q_last^-1 mod q_l) * R
+            std::memcpy(rs[l].qlast_inv_m.l, inv_m.w, 32);
+        }
+        if ((rc = upload(h, rs, &h->d_rescale))) return rc;
+    }
+    const size_t count = (size_t)batch * h->n;
+    hipLaunchKernelGGL(fhe_dev::rescale_drop_last_kernel, dim3(ew_grid(count)), dim3(256), 0, h->stream, (fhe_dev::u256 *)d_out,
+                       (const fhe_dev::u256 *)d_in, (const fhe_dev::CrtLimb *)h->d_crt, (const fhe_dev::RescaleLimb *)h->d_rescale, h->L, h->log_n, count);
+    return post_launch(h->stream, "rescale_drop_last_kernel");
 }
 
 // ------------------------------------------------------------------------------------------------------

@@ -211,6 +211,7 @@ struct CrtLimb {
     uint64_t inv0, _pad;
 };
 struct CrtBig { u256 Q; uint64_t inv0, _pad; };
+struct RescaleLimb { u256 qlast_inv_m; };   // (q_last^-1 mod q_l) * R mod q_l
 
 // rns[b][l][x] = values[b][x] mod q_l : mont(mont(v, R^2), 1) is exact for ANY 256-bit v (the sum before the final
 // subtraction is below 2q).  One lane per (b, x); the L residues are produced from one load of the value.
@@ -241,6 +242,37 @@ from_rns_kernel(u256 *__restrict__ values, const u256 *__restrict__ rns, const C
             acc = add_mod(acc, mont_mul(t, P.Mi_mQ, big.Q, big.inv0), big.Q);
         }
         store_u256(values + g, acc);
+    }
+}
+
+// Modulus switching by dropping the last prime (rns_mod_switch_kernel, include/rns.cuh:128-136, undefined in the reference):
+// out[b][l][x] = (c[b][l][x] - r) * q_last^-1 mod q_l with r the centred residue modulo q_last, i.e. round(C / q_last) limb-wise.
+// One lane per (b, x): the last limb is read once and all L-1 outputs are produced from it.
+__global__ void __launch_bounds__(256)
+rescale_drop_last_kernel(u256 *__restrict__ out, const u256 *__restrict__ in, const CrtLimb *__restrict__ limbs,
+                         const RescaleLimb *__restrict__ rs, uint32_t L, uint32_t log_n, size_t count) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x, n = (size_t)1 << log_n;
+    u256 one; one.l[0] = 1; one.l[1] = one.l[2] = one.l[3] = 0;
+    const u256 ql = limbs[L - 1].q;
+    u256 half;                                                       // floor(q_last / 2)
+#pragma unroll
+    for (int i = 0; i < 4; i++) half.l[i] = (ql.l[i] >> 1) | (i < 3 ? ql.l[i + 1] << 63 : 0);
+    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < count; g += stride) {
+        const size_t b = g >> log_n, x = g & (n - 1);
+        const u256 cl = load_u256(in + (b * L + (L - 1)) * n + x);
+        u256 d; sub256(d, half, cl);                                 // borrow <=> cl > half
+        bool neg = false;
+#pragma unroll
+        for (int i = 3; i >= 0; i--) { if (cl.l[i] != half.l[i]) { neg = cl.l[i] > half.l[i]; break; } }
+        u256 mag;
+        if (neg) sub256(mag, ql, cl); else mag = cl;
+        for (uint32_t l = 0; l + 1 < L; l++) {
+            const CrtLimb &P = limbs[l];
+            u256 r = mont_mul(mont_mul(mag, P.r2, P.q, P.inv0), one, P.q, P.inv0);          // |r| mod q_l
+            if (neg && (r.l[0] | r.l[1] | r.l[2] | r.l[3])) { u256 z; sub256(z, P.q, r); r = z; }
+            const u256 diff = sub_mod(load_u256(in + (b * L + l) * n + x), r, P.q);
+            store_u256(out + (b * (L - 1) + l) * n + x, mont_mul(diff, rs[l].qlast_inv_m, P.q, P.inv0));
+        }
     }
 }
 

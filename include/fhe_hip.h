@@ -146,6 +146,12 @@ int fhe_rns_to_rns(fhe_rns_ntt_t *h, void *d_rns, const void *d_values, uint32_t
  * reconstruction into [0, Q), Q = prod q_l.  Needs Q < 2^255 (FHE_ERR_UNSUPPORTED otherwise). */
 int fhe_rns_from_rns(fhe_rns_ntt_t *h, void *d_values, const void *d_rns, uint32_t batch);
 
+/* RNSContext::mod_switch_rns / rns_mod_switch_kernel (include/rns.cuh:44,128-136), FHEContext::mod_switch_to_next
+ * (include/fhe.cuh:109), poly_mod_switch_kernel (include/polynomial.cuh:96-103) -- all undefined in the reference:
+ * drop the last prime with rounding, d_out[b][l][x] = round(C / q_last) mod q_l for l < L-1.  d_in is [batch][L][n],
+ * d_out is [batch][L-1][n] (the layout of an engine built on the first L-1 primes).  Needs L >= 2. */
+int fhe_rns_rescale_drop_last(fhe_rns_ntt_t *h, void *d_out, const void *d_in, uint32_t batch);
+
 /* ---- relinearisation / key switching ------------------------------------------ */
 /* RelinKeys (include/fhe.cuh:52-55) as produced by FHEContext::relinkey_gen (src/fhe.cu:76-111):
  * key pairs (b, a) with b = -a*s + e + g*s^2, one per decomposition level.  In the RNS representation every residue

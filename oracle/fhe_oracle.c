@@ -543,3 +543,32 @@ int orc_from_rns(orc_plan *const *plans, uint32_t L, orc_u256 *values, const orc
     free(Mi_m); free(inv_m);
     return 0;
 }
+
+/* ------------------------------------------------------------------------------------------ */
+static int u256_gt(const orc_u256 *a, const orc_u256 *b) {        /* a > b */
+    for (int i = 3; i >= 0; i--) { if (a->limbs[i] != b->limbs[i]) return a->limbs[i] > b->limbs[i]; }
+    return 0;
+}
+void orc_rescale_drop_last(orc_plan *const *plans, uint32_t L, orc_u256 *out, const orc_u256 *in, uint32_t batch) {
+    const uint32_t n = plans[0]->n;
+    const orc_plan *pl = plans[L - 1];
+    orc_u256 half = pl->q; u256_shr(&half, 1);                       /* floor(q_last / 2) */
+    for (uint32_t l = 0; l + 1 < L; l++) {
+        const orc_plan *p = plans[l];
+        /* q_last^-1 mod q_l in Montgomery form: (q_last mod q_l)^(q_l - 2) */
+        orc_u256 ql_m, inv_m, e = p->q; e.limbs[0] -= 2;
+        orc_mont_mul(&ql_m, &pl->q, &p->r2, &p->q, p->inv0);
+        pow_mont(p, &inv_m, &ql_m, &e);
+        for (uint32_t b = 0; b < batch; b++)
+            for (uint32_t x = 0; x < n; x++) {
+                const orc_u256 *cl = &in[((size_t)b * L + (L - 1)) * n + x];
+                orc_u256 mag, t, r_l, d;
+                const int neg = u256_gt(cl, &half);                /* centred residue r = cl - q_last < 0 */
+                if (neg) sub256(mag.limbs, pl->q.limbs, cl->limbs); else mag = *cl;
+                orc_mont_mul(&t, &mag, &p->r2, &p->q, p->inv0); from_mont(p, &r_l, &t);     /* |r| mod q_l */
+                if (neg && !u256_is_zero(&r_l)) { orc_u256 z; sub256(z.limbs, p->q.limbs, r_l.limbs); r_l = z; }
+                orc_sub_mod(&d, &in[((size_t)b * L + l) * n + x], &r_l, &p->q);
+                orc_mont_mul(&out[((size_t)b * (L - 1) + l) * n + x], &d, &inv_m, &p->q, p->inv0);
+            }
+    }
+}

@@ -116,6 +116,12 @@ int orc_relinearize(orc_plan *const *plans, uint32_t L, uint32_t decomp_bits, or
  * SURVEY D12) and the CRT reconstruction values[x] = sum_l [r_l * (Q/q_l)^-1]_{q_l} * (Q/q_l) mod Q, Q = prod q_l < 2^255. */
 void orc_to_rns(orc_plan *const *plans, uint32_t L, orc_u256 *rns, const orc_u256 *values, uint32_t batch);
 int orc_from_rns(orc_plan *const *plans, uint32_t L, orc_u256 *values, const orc_u256 *rns, uint32_t batch);
+/* Modulus switching in RNS -- RNSContext::mod_switch_rns / rns_mod_switch_kernel (include/rns.cuh:44,128-136, undefined),
+ * FHEContext::mod_switch_to_next (include/fhe.cuh:109, undefined), poly_mod_switch_kernel ("scale by new/old and round",
+ * include/polynomial.cuh:96-103, undefined).  Dropping the last prime: out = round(c / q_last) taken limb-wise,
+ *   out[l][x] = (c[l][x] - r[x]) * q_last^-1 mod q_l,  r = the centred residue of c modulo q_last (|r| <= q_last / 2),
+ * which equals (C - r) / q_last for the CRT integer C.  in: [batch][L][n], out: [batch][L-1][n]. */
+void orc_rescale_drop_last(orc_plan *const *plans, uint32_t L, orc_u256 *out, const orc_u256 *in, uint32_t batch);
 int orc_max_threads(void);
 
 #ifdef __cplusplus

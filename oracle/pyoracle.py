@@ -74,6 +74,7 @@ def lib():
             "orc_max_threads": (ci, []),
             "orc_to_rns": (None, [ctypes.POINTER(vp), u32, P, P, u32]),
             "orc_from_rns": (ci, [ctypes.POINTER(vp), u32, P, P, u32]),
+            "orc_rescale_drop_last": (None, [ctypes.POINTER(vp), u32, P, P, u32]),
             "orc_relin_num_digits": (u32, [ctypes.POINTER(vp), u32, u32]),
             "orc_relinearize": (ci, [ctypes.POINTER(vp), u32, u32, P, P, P, ctypes.POINTER(P), ctypes.POINTER(P), u32, ci]),
         }
@@ -306,6 +307,14 @@ def _rns_from_rns(self, rns):
     return out
 
 
+def _rns_rescale(self, rns):
+    """[batch][L][n] -> [batch][L-1][n]: round(c / q_last), limb-wise."""
+    batch = self._batch(rns); assert self.L >= 2
+    out = np.empty((batch, self.L - 1, self.n, 4), np.uint64)
+    lib().orc_rescale_drop_last(self._arr, self.L, _p(out), _p(np.ascontiguousarray(rns)), batch); return out
+
+
+RnsPlan.rescale_drop_last = _rns_rescale
 RnsPlan.to_rns = _rns_to_rns
 RnsPlan.from_rns = _rns_from_rns
 RnsPlan.relinearize = _rns_relin

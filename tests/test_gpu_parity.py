@@ -630,3 +630,22 @@ def test_largest_lds_size_tensor_and_keyswitch(eng, oracle):
     e.relinearize(rk, c[0], c[1], c[2], 1)
     r0, r1 = rp.relinearize(w, w0, w1, w2, kb, ka, threads=8)
     assert np.array_equal(c[0].download(a0.shape), r0) and np.array_equal(c[1].download(a0.shape), r1)
+
+
+@pytest.mark.parametrize("n,bits,L", [(8192, 30, 4), (2048, 60, 3), (64, 120, 2), (4096, 40, 6), (1024, 30, 2)])
+def test_rescale_drop_last_matches_oracle(eng, oracle, n, bits, L):
+    """Modulus switching by dropping the last prime (rounded division), then the result is usable by an engine on L-1 primes."""
+    moduli = nm.ntt_primes(bits, n, L)
+    e = eng.RnsNttEngine(n, moduli); rp = oracle.RnsPlan(n, moduli)
+    batch = 3
+    c = rns_poly(401, moduli, n, batch)
+    for l, q in enumerate(moduli):                      # exercise both signs of the centred remainder and its extremes
+        c[0, l, :4] = oracle.to_limbs([0, q - 1, q // 2, q // 2 + 1])
+    dIn = _up(eng, c); dOut = eng.DeviceBuffer(batch * (L - 1) * n * 32)
+    e.rescale_drop_last(dOut, dIn, batch)
+    got = dOut.download((batch, L - 1, n, 4))
+    assert np.array_equal(got, rp.rescale_drop_last(c))
+    assert np.array_equal(dIn.download(c.shape), c)
+    e2 = eng.RnsNttEngine(n, moduli[:-1]); e2.check_canonical(dOut, batch)
+    with pytest.raises(eng.FheError):
+        eng.RnsNttEngine(n, moduli[:1]).rescale_drop_last(dOut, dIn, 1)

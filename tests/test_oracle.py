@@ -296,3 +296,27 @@ def test_crt_rejects_too_large_bases(oracle):
     rp = oracle.RnsPlan(n, nm.ntt_primes(60, n, 5))            # 300 bits
     with pytest.raises(ValueError):
         rp.from_rns(np.zeros((1, 5, n, 4), np.uint64))
+
+
+@pytest.mark.parametrize("n,bits,L", [(16, 30, 3), (16, 60, 2), (8, 120, 2), (16, 30, 5)])
+def test_rescale_drop_last_is_rounded_division(oracle, n, bits, L):
+    """(C - r) / q_last with the centred remainder r, i.e. round(C / q_last), limb-wise."""
+    moduli = nm.ntt_primes(bits, n, L)
+    Q = 1
+    for q in moduli:
+        Q *= q
+    ql = moduli[-1]
+    rp = oracle.RnsPlan(n, moduli)
+    rng = random.Random(bits + L)
+    vals = [rng.randrange(Q) for _ in range(2 * n - 4)] + [0, Q - 1, ql // 2, ql // 2 + 1]
+    R = rp.to_rns(oracle.to_limbs(vals).reshape(2, n, 4))
+    out = rp.rescale_drop_last(R)
+    for b in range(2):
+        for i, C in enumerate(vals[b * n:(b + 1) * n]):
+            r = C % ql
+            if r > ql // 2:
+                r -= ql
+            want = (C - r) // ql
+            assert (C - r) % ql == 0 and abs(want * ql - C) <= ql // 2
+            for l, q in enumerate(moduli[:-1]):
+                assert oracle.from_limbs(out[b, l, i:i + 1])[0] == want % q
