@@ -5,6 +5,7 @@
 #pragma once
 #include <algorithm>
 #include <memory>
+#include <random>
 #include <vector>
 
 #include "polynomial.hpp"
@@ -33,6 +34,11 @@ struct RelinKeys {                                            // include/fhe.cuh
     ~RelinKeys() { fhe_relin_keys_destroy(imported); for (PublicKey *k : rlk_keys) { if (k) { delete k->pk0; delete k->pk1; delete k; } } }
 };
 
+struct Plaintext {                                            // include/fhe.cuh:72-75
+    Polynomial *poly = nullptr;
+    bool is_ntt_form = false;
+};
+
 struct Ciphertext {                                           // include/fhe.cuh:63-69
     std::vector<Polynomial *> components;
     uint32_t level = 0;
@@ -44,6 +50,7 @@ struct SchemeParams {                                         // include/fhe.cuh
     SecurityParams security;
     uint32_t n;
     std::vector<uint256_t> rns_moduli;     // q = prod(rns_moduli); the reference hard-codes the even q = 2^60 (src/fhe.cu:13)
+    uint64_t t = 65537;                    // plaintext modulus (src/fhe.cu:14); t = 1 (mod 2n) gives n SIMD slots
     RNS_NTTEngine *rns_ntt;
 };
 
@@ -169,10 +176,172 @@ public:
             }
     }
 
+    // ---- scheme plumbing: BGV-flavoured so that tensor product + relinearisation decrypt correctly --------
+    // (the reference's keygen / encrypt / decrypt, src/fhe.cu:54-185, mix BFV scaling with an even modulus and call
+    // undefined kernels; here noise is a multiple of t and plaintexts sit in the low bits: c0 + c1*s = m + t*e).
+    // Sampling is done on the host with a seeded std::mt19937_64 (the reference's device samplers are toys, out of scope).
+    void seed(uint64_t s) { rng_.seed(s); }
+
+    void keygen(PublicKey &pk, SecretKey &sk) {                                            // src/fhe.cu:54-74
+        sk.sk = new_polynomial(); pk.pk0 = new_polynomial(); pk.pk1 = new_polynomial();
+        upload_signed(*sk.sk, sample_small(1));                                             // ternary secret (:57)
+        upload_uniform(*pk.pk1);                                                            // :64
+        std::unique_ptr<Polynomial> as(new_polynomial());
+        params_.rns_ntt->multiply_rns(as->coeffs, pk.pk1->coeffs, sk.sk->coeffs);           // :71
+        upload_signed(*pk.pk0, sample_small(3), params_.t);                                 // t*e (:67-68)
+        params_.rns_ntt->sub_rns(pk.pk0->coeffs, pk.pk0->coeffs, as->coeffs);               // pk0 = t*e - pk1*sk (:72)
+        device_synchronize();
+    }
+
+    void relinkey_gen(RelinKeys &rlk, const SecretKey &sk, uint32_t decomp_bits = 16) {    // src/fhe.cu:76 signature
+        relinkey_gen(rlk, sk, decomp_bits, rng_, params_.t);
+    }
+
+    // SIMD-slot encoding (the reference's encode scales by delta, src/fhe.cu:113-136, and its BatchEncoder is a passthrough,
+    // :267-279; the expectations of its test -- element-wise products -- need real slots): m(zeta_i) = values[i].
+    void encode(Plaintext &pt, const std::vector<uint64_t> &values) {
+        const uint32_t n = params_.n; const uint64_t t = params_.t;
+        if ((t - 1) % (2ull * n)) throw std::runtime_error("FHEContext::encode: t must be 1 (mod 2n) for slot encoding");
+        std::vector<uint64_t> m(n, 0);
+        for (size_t i = 0; i < values.size() && i < n; i++) m[i] = values[i] % t;
+        slot_transform(m, true);
+        std::vector<long long> sm(m.begin(), m.end());
+        if (!pt.poly) pt.poly = new_polynomial();
+        upload_signed(*pt.poly, sm);
+        pt.is_ntt_form = false;
+    }
+    void decode(std::vector<uint64_t> &values, const Plaintext &pt) {
+        const uint32_t n = params_.n, L = (uint32_t)params_.rns_moduli.size();
+        std::vector<uint256_t> h((size_t)L * n);
+        device_synchronize(); copy_to_host(h.data(), pt.poly->coeffs, h.size());
+        values.assign(n, 0);
+        for (uint32_t i = 0; i < n; i++) values[i] = h[i].limbs[0] % params_.t;              // plaintexts are stored reduced mod t in every limb
+        slot_transform(values, false);
+    }
+
+    void encrypt(Ciphertext &ct, const Plaintext &pt, const PublicKey &pk) {               // src/fhe.cu:138-169
+        ensure_components(ct, 2);
+        RNS_NTTEngine &E = *params_.rns_ntt;
+        std::unique_ptr<Polynomial> u(new_polynomial()), e(new_polynomial());
+        upload_signed(*u, sample_small(1));
+        E.multiply_rns(ct.components[0]->coeffs, pk.pk0->coeffs, u->coeffs);                 // pk0*u (:160)
+        E.multiply_rns(ct.components[1]->coeffs, pk.pk1->coeffs, u->coeffs);                 // pk1*u (:165)
+        upload_signed(*e, sample_small(3), params_.t);
+        E.add_rns(ct.components[0]->coeffs, ct.components[0]->coeffs, e->coeffs);            // + t*e1
+        E.add_rns(ct.components[0]->coeffs, ct.components[0]->coeffs, pt.poly->coeffs);      // + m  (:161-162)
+        device_synchronize();
+        upload_signed(*e, sample_small(3), params_.t);
+        E.add_rns(ct.components[1]->coeffs, ct.components[1]->coeffs, e->coeffs);            // + t*e2 (:166)
+        device_synchronize();
+        ct.level = 0; ct.noise_budget = 0; ct.is_ntt_form = false;
+    }
+
+    // c0 + c1*s (+ c2*s^2), CRT to the centred integer through fhe_rns_from_rns, reduced mod t  (src/fhe.cu:171-185)
+    void decrypt(Plaintext &pt, const Ciphertext &ct, const SecretKey &sk) {
+        const uint32_t n = params_.n, L = (uint32_t)params_.rns_moduli.size();
+        RNS_NTTEngine &E = *params_.rns_ntt;
+        std::unique_ptr<Polynomial> acc(new_polynomial()), sp(new_polynomial()), tmp(new_polynomial());
+        check(fhe_hip_memcpy_d2d(acc->coeffs, ct.components[0]->coeffs, acc->count() * sizeof(uint256_t)), "decrypt copy");
+        check(fhe_hip_memcpy_d2d(sp->coeffs, sk.sk->coeffs, sp->count() * sizeof(uint256_t)), "decrypt copy");
+        for (size_t k = 1; k < ct.components.size(); k++) {
+            E.multiply_rns(tmp->coeffs, ct.components[k]->coeffs, sp->coeffs);
+            E.add_rns(acc->coeffs, acc->coeffs, tmp->coeffs);
+            if (k + 1 < ct.components.size()) E.multiply_rns(sp->coeffs, sp->coeffs, sk.sk->coeffs);   // s^(k+1), in place
+        }
+        uint256_t *d_int = device_alloc(n);
+        E.from_rns(d_int, acc->coeffs);
+        std::vector<uint256_t> v(n);
+        device_synchronize(); copy_to_host(v.data(), d_int, n); device_free(d_int);
+        // Q and Q/2 as 256-bit integers
+        uint64_t Q[4] = {1, 0, 0, 0};
+        for (uint32_t l = 0; l < L; l++) mul_small(Q, params_.rns_moduli[l].limbs[0]);
+        uint64_t half[4]; for (int i = 0; i < 4; i++) half[i] = (Q[i] >> 1) | (i < 3 ? Q[i + 1] << 63 : 0);
+        const uint64_t t = params_.t, q_mod_t = mod_small(Q, t);
+        std::vector<long long> m(n);
+        for (uint32_t i = 0; i < n; i++) {
+            const uint64_t r = mod_small(v[i].limbs, t);
+            m[i] = (long long)(greater(v[i].limbs, half) ? (r + t - q_mod_t) % t : r);         // value - Q when above Q/2
+        }
+        if (!pt.poly) pt.poly = new_polynomial();
+        upload_signed(*pt.poly, m);
+        pt.is_ntt_form = false;
+    }
+
     const SchemeParams &params() const { return params_; }
 
 private:
     SchemeParams params_;
+    std::mt19937_64 rng_{0x5EED0000ull};
+
+    // ---- host-side helpers of the plumbing above --------------------------------------------------------------------------
+    std::vector<long long> sample_small(int bound) {
+        std::vector<long long> v(params_.n);
+        for (auto &x : v) x = (long long)(rng_() % (2 * bound + 1)) - bound;
+        return v;
+    }
+    // signed integers (times `scale`) -> residues in every limb -> device
+    void upload_signed(Polynomial &p, const std::vector<long long> &v, uint64_t scale = 1) {
+        const uint32_t n = params_.n, L = (uint32_t)params_.rns_moduli.size();
+        std::vector<uint256_t> h((size_t)L * n);
+        for (uint32_t l = 0; l < L; l++) {
+            const uint64_t q = params_.rns_moduli[l].limbs[0];
+            for (uint32_t i = 0; i < n; i++) {
+                const uint64_t mag = (uint64_t)((unsigned __int128)(uint64_t)(v[i] < 0 ? -v[i] : v[i]) % q * (scale % q) % q);
+                h[(size_t)l * n + i] = uint256_t(v[i] < 0 ? (q - mag) % q : mag);
+            }
+        }
+        copy_to_device(p.coeffs, h.data(), h.size());
+    }
+    void upload_uniform(Polynomial &p) {
+        const uint32_t n = params_.n, L = (uint32_t)params_.rns_moduli.size();
+        std::vector<uint256_t> h((size_t)L * n);
+        for (uint32_t l = 0; l < L; l++) for (uint32_t i = 0; i < n; i++) h[(size_t)l * n + i] = uint256_t(rng_() % params_.rns_moduli[l].limbs[0]);
+        copy_to_device(p.coeffs, h.data(), h.size());
+    }
+    static uint64_t pow_mod(uint64_t b, uint64_t e, uint64_t m) {
+        unsigned __int128 acc = 1, bb = b % m;
+        for (; e; e >>= 1) { if (e & 1) acc = acc * bb % m; bb = bb * bb % m; }
+        return (uint64_t)acc;
+    }
+    // forward = false: coefficients -> values at the odd powers of a primitive 2n-th root mod t; forward = true: the inverse map.
+    // O(n^2 / 64)-free: a plain O(n log n) negacyclic NTT over Z_t on the host.
+    void slot_transform(std::vector<uint64_t> &a, bool inverse) const {
+        const uint32_t n = params_.n; const uint64_t t = params_.t;
+        uint64_t g = 2;                                           // find a generator-derived primitive 2n-th root of unity mod t
+        uint64_t psi = 0;
+        for (;; g++) { psi = pow_mod(g, (t - 1) / (2ull * n), t); if (pow_mod(psi, n, t) == t - 1) break; }
+        const uint64_t ipsi = pow_mod(psi, 2ull * n - 1, t), ninv = pow_mod(n, t - 2, t);
+        auto mulm = [t](uint64_t x, uint64_t y) { return (uint64_t)((unsigned __int128)x * y % t); };
+        if (!inverse) { uint64_t pw = 1; for (uint32_t i = 0; i < n; i++) { a[i] = mulm(a[i], pw); pw = mulm(pw, psi); } }   // twist
+        // cyclic NTT with omega = psi^2 (or its inverse), bit-reversal + iterative Cooley-Tukey
+        const uint64_t omega = inverse ? mulm(ipsi, ipsi) : mulm(psi, psi);
+        uint32_t lg = 0; while ((1u << lg) < n) lg++;
+        for (uint32_t i = 0; i < n; i++) { uint32_t r = 0; for (uint32_t b = 0; b < lg; b++) r |= ((i >> b) & 1) << (lg - 1 - b); if (i < r) std::swap(a[i], a[r]); }
+        for (uint32_t len = 2; len <= n; len <<= 1) {
+            const uint64_t wl = pow_mod(omega, n / len, t);
+            for (uint32_t i = 0; i < n; i += len) {
+                uint64_t w = 1;
+                for (uint32_t j = 0; j < len / 2; j++) {
+                    const uint64_t u = a[i + j], v = mulm(a[i + j + len / 2], w);
+                    a[i + j] = (u + v) % t; a[i + j + len / 2] = (u + t - v) % t; w = mulm(w, wl);
+                }
+            }
+        }
+        if (inverse) { uint64_t pw = 1; for (uint32_t i = 0; i < n; i++) { a[i] = mulm(mulm(a[i], ninv), pw); pw = mulm(pw, ipsi); } }   // untwist, scale
+    }
+    static void mul_small(uint64_t x[4], uint64_t m) {
+        unsigned __int128 c = 0;
+        for (int i = 0; i < 4; i++) { c += (unsigned __int128)x[i] * m; x[i] = (uint64_t)c; c >>= 64; }
+    }
+    static uint64_t mod_small(const uint64_t x[4], uint64_t m) {
+        unsigned __int128 r = 0;
+        for (int i = 3; i >= 0; i--) r = ((r << 64) | x[i]) % m;
+        return (uint64_t)r;
+    }
+    static bool greater(const uint64_t a[4], const uint64_t b[4]) {
+        for (int i = 3; i >= 0; i--) if (a[i] != b[i]) return a[i] > b[i];
+        return false;
+    }
 
     void init(const SecurityParams &params, const std::vector<uint256_t> &moduli) {
         params_.security = params;

@@ -234,6 +234,47 @@ static void test_fhe_multiply_relinearize() {
     std::cout << "  Dec(relin(Enc(m1) x Enc(m2))) == m1 (*) m2 mod " << t << " on all " << N << " coefficients" << std::endl;
 }
 
+
+// tests/test_fhe.cu:169-273 through the mirror's FHEContext alone: keygen, relinkey_gen(16), encode {5,10,15,20} and
+// {3,6,9,12}, encrypt, add / multiply (+ relinearize), decrypt, decode -- and the expectations the reference only prints
+// (8 16 24 32 and 15 60 135 240) are asserted.
+static void test_fhe_operations() {
+    std::cout << "Testing FHE Operations (reference scenario through the mirror)..." << std::endl;
+    SecurityParams sp{128, 4096, 120, 3.2f, 64};
+    FHEContext ctx(sp);
+    ctx.seed(2026);
+    PublicKey pk; SecretKey sk; RelinKeys rlk;
+    ctx.keygen(pk, sk);
+    ctx.relinkey_gen(rlk, sk, 16);
+    REQUIRE(rlk.rlk_keys.size() == 8);                                     // 4 limbs x 2 digits of 16 bits
+    Plaintext pa, pb, pr;
+    ctx.encode(pa, {5, 10, 15, 20});
+    ctx.encode(pb, {3, 6, 9, 12});
+    std::vector<uint64_t> back; ctx.decode(back, pa);
+    REQUIRE(back[0] == 5 && back[1] == 10 && back[2] == 15 && back[3] == 20 && back[4] == 0);
+    Ciphertext ca, cb, csum, cprod;
+    ctx.encrypt(ca, pa, pk); ctx.encrypt(cb, pb, pk);
+    std::vector<uint64_t> out;
+    ctx.decrypt(pr, ca, sk); ctx.decode(out, pr);
+    REQUIRE(out[0] == 5 && out[1] == 10 && out[2] == 15 && out[3] == 20);
+    ctx.add(csum, ca, cb);
+    ctx.decrypt(pr, csum, sk); ctx.decode(out, pr);
+    std::cout << "  Addition result: " << out[0] << " " << out[1] << " " << out[2] << " " << out[3] << " (expected: 8 16 24 32)" << std::endl;
+    REQUIRE(out[0] == 8 && out[1] == 16 && out[2] == 24 && out[3] == 32);
+    ctx.multiply(cprod, ca, cb, rlk);
+    REQUIRE(cprod.components.size() == 2);
+    ctx.decrypt(pr, cprod, sk); ctx.decode(out, pr);
+    std::cout << "  Multiplication result: " << out[0] << " " << out[1] << " " << out[2] << " " << out[3] << " (expected: 15 60 135 240)" << std::endl;
+    REQUIRE(out[0] == 15 && out[1] == 60 && out[2] == 135 && out[3] == 240);
+    for (size_t i = 4; i < out.size(); i++) REQUIRE(out[i] == 0);
+    // depth 2: (a*b)*a = 75 600 2025 4800
+    Ciphertext c3;
+    ctx.multiply(c3, cprod, ca, rlk);
+    ctx.decrypt(pr, c3, sk); ctx.decode(out, pr);
+    REQUIRE(out[0] == 75 && out[1] == 600 && out[2] == 2025 && out[3] == 4800);
+    delete pk.pk0; delete pk.pk1; delete sk.sk; delete pa.poly; delete pb.poly; delete pr.poly;
+}
+
 // tests/test_fhe.cu:275-318 shape (N = 8192), timing the multiply path instead of encrypt
 static void benchmark_multiply() {
     std::cout << "Benchmark: ciphertext tensor product, N = 8192, log_q = 120" << std::endl;
@@ -264,6 +305,7 @@ int main(int argc, char **argv) {
     test_polynomial_multiplication();
     test_fhe_multiply();
     test_fhe_multiply_relinearize();
+    test_fhe_operations();
     benchmark_multiply();
     std::cout << "ALL PASSED" << std::endl;
     return 0;
