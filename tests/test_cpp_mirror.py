@@ -41,3 +41,34 @@ def test_cpp_mirror_reference_scenarios_on_gpu(pkg):
     print(res.stdout)
     assert res.returncode == 0, res.stdout + res.stderr
     assert "ALL PASSED" in res.stdout
+
+
+GRAPH_SRC = os.path.join(ROOT, "tests", "cpp", "test_graph_capture.cpp")
+GRAPH_EXE = os.path.join(OUT_DIR, "test_graph_capture")
+
+
+def _build_graph_test(pkg):
+    pkg.build_library()
+    lib_dir = os.path.dirname(pkg.library_path())
+    os.makedirs(OUT_DIR, exist_ok=True)
+    if os.path.exists(GRAPH_EXE) and os.path.getmtime(GRAPH_EXE) >= max(os.path.getmtime(GRAPH_SRC), os.path.getmtime(os.path.join(ROOT, "include", "fhe_hip.h"))):
+        return GRAPH_EXE
+    cmd = ["/opt/rocm/bin/hipcc", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "include"), GRAPH_SRC, "-L", lib_dir, "-lfhe_hip",
+           f"-Wl,-rpath,{lib_dir}", "-o", GRAPH_EXE]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+    return GRAPH_EXE
+
+
+def test_graph_capture_test_compiles(pkg):
+    _build_graph_test(pkg)
+
+
+@pytest.mark.gpu
+def test_engine_launches_are_graph_capturable(pkg):
+    """Tensor product + relinearisation captured into a hipGraph on a caller-owned stream and replayed."""
+    exe = _build_graph_test(pkg)
+    res = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    print(res.stdout)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert "graph capture ok" in res.stdout
