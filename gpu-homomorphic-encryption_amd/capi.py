@@ -75,6 +75,7 @@ def lib():
         "fhe_rns_check_canonical": ([vp, vp, u32], ci),
         "fhe_rns_to_rns": ([vp, vp, vp, u32], ci),
         "fhe_rns_from_rns": ([vp, vp, vp, u32], ci),
+        "fhe_rns_fast_base_convert": ([vp, vp, vp, vp, u32], ci),
         "fhe_rns_rescale_drop_last": ([vp, vp, vp, u32], ci),
         "fhe_relin_num_digits": ([vp, u32, P(u32)], ci),
         "fhe_relin_keys_create": ([vp, P(vp), u32, P(vp), P(vp), u32], ci),
@@ -288,6 +289,9 @@ class RnsNttEngine:
 
     def from_rns(self, d_values, d_rns, batch=1):
         _check(lib().fhe_rns_from_rns(self.h, _ptr(d_values), _ptr(d_rns), batch))
+
+    def fast_base_convert(self, target, d_out, d_in, batch=1):
+        _check(lib().fhe_rns_fast_base_convert(self.h, target.h, _ptr(d_out), _ptr(d_in), batch))
 
     def rescale_drop_last(self, d_out, d_in, batch=1):
         _check(lib().fhe_rns_rescale_drop_last(self.h, _ptr(d_out), _ptr(d_in), batch))

@@ -190,6 +190,8 @@ struct fhe_rns_ntt {
     std::vector<U256> moduli;
     void *d_crt = nullptr;               // CrtLimb[L], built on first use of to_rns / from_rns (owned by d_tables)
     void *d_rescale = nullptr;           // RescaleLimb[L-1], built on first use of rescale_drop_last (owned by d_tables)
+    void *d_bconv = nullptr;             // ((Q/q_i) mod p_j) * R_j for the most recent base-conversion target (owned by d_tables)
+    const void *bconv_target = nullptr;
     fhe_dev::CrtBig crt_big;
     int crt_state = 0;                   // 0 = not built, 1 = ready, -1 = Q too large for from_rns (to_rns still fine)
 };
@@ -831,6 +833,32 @@ extern "C" int fhe_rns_rescale_drop_last(fhe_rns_ntt_t *h, void *d_out, const vo
     hipLaunchKernelGGL(fhe_dev::rescale_drop_last_kernel, dim3(ew_grid(count)), dim3(256), 0, h->stream, (fhe_dev::u256 *)d_out,
                        (const fhe_dev::u256 *)d_in, (const fhe_dev::CrtLimb *)h->d_crt, (const fhe_dev::RescaleLimb *)h->d_rescale, h->L, h->log_n, count);
     return post_launch(h->stream, "rescale_drop_last_kernel");
+}
+
+
+extern "C" int fhe_rns_fast_base_convert(fhe_rns_ntt_t *h, fhe_rns_ntt_t *target, void *d_out, const void *d_in, uint32_t batch) {
+    int rc = check_call(h, batch, "fast_base_convert"); if (rc) return rc;
+    if (!target || !d_out || !d_in || d_out == d_in) return fail(FHE_ERR_INVALID_ARG, "fast_base_convert: null or aliased argument");
+    if (target->n != h->n) return fail(FHE_ERR_INVALID_ARG, "fast_base_convert: source and target engines differ in degree");
+    if ((rc = ensure_crt(h)) || (rc = ensure_crt(target))) return rc;
+    if (h->bconv_target != target) {
+        std::vector<fhe_dev::u256> mat((size_t)h->L * target->L);
+        for (uint32_t j = 0; j < target->L; j++) {
+            fhe_host::Mod M(target->moduli[j]);
+            for (uint32_t i = 0; i < h->L; i++) {
+                U256 acc = M.r1;                                              // prod_{k != i} q_k mod p_j, Montgomery form
+                for (uint32_t k = 0; k < h->L; k++) if (k != i) acc = M.mont(acc, M.to_mont(M.reduce(h->moduli[k])));
+                std::memcpy(mat[(size_t)i * target->L + j].l, acc.w, 32);
+            }
+        }
+        if ((rc = upload(h, mat, &h->d_bconv))) return rc;                    // earlier matrices stay owned by d_tables until destroy
+        h->bconv_target = target;
+    }
+    const size_t count = (size_t)batch * h->n;
+    hipLaunchKernelGGL(fhe_dev::fast_base_convert_kernel, dim3(ew_grid(count)), dim3(256), 0, h->stream, (fhe_dev::u256 *)d_out,
+                       (const fhe_dev::u256 *)d_in, (const fhe_dev::CrtLimb *)h->d_crt, h->L, (const fhe_dev::CrtLimb *)target->d_crt, target->L,
+                       (const fhe_dev::u256 *)h->d_bconv, h->log_n, count);
+    return post_launch(h->stream, "fast_base_convert_kernel");
 }
 
 // ------------------------------------------------------------------------------------------------------

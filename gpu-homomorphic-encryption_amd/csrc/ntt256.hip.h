@@ -276,4 +276,30 @@ rescale_drop_last_kernel(u256 *__restrict__ out, const u256 *__restrict__ in, co
     }
 }
 
+// Fast base conversion (Bajard et al.; fast_base_conversion_kernel, include/rns.cuh:116-125, undefined in the reference):
+// out[b][j][x] = sum_i [x_i * (Q/q_i)^-1]_{q_i} * (Q/q_i) mod p_j.  `mat` holds ((Q/q_i) mod p_j) * R_j, row-major [L][Lp].
+// One lane per (b, x): the L scaled residues t_i are formed once and reused for every target prime.
+constexpr int BASE_CONV_MAX_L = 16;
+__global__ void __launch_bounds__(256)
+fast_base_convert_kernel(u256 *__restrict__ out, const u256 *__restrict__ in, const CrtLimb *__restrict__ src, uint32_t L,
+                         const CrtLimb *__restrict__ dst, uint32_t Lp, const u256 *__restrict__ mat, uint32_t log_n, size_t count) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x, n = (size_t)1 << log_n;
+    u256 one; one.l[0] = 1; one.l[1] = one.l[2] = one.l[3] = 0;
+    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < count; g += stride) {
+        const size_t b = g >> log_n, x = g & (n - 1);
+        for (uint32_t j = 0; j < Lp; j++) {
+            const CrtLimb &D = dst[j];
+            u256 acc; acc.l[0] = acc.l[1] = acc.l[2] = acc.l[3] = 0;
+            for (uint32_t i = 0; i < L; i++) {
+                const CrtLimb &S = src[i];
+                const u256 ti = mont_mul(load_u256(in + (b * L + i) * n + x), S.minv_m, S.q, S.inv0);      // [x_i * M_i^-1]_{q_i}
+                const u256 ti_m = mont_mul(ti, D.r2, D.q, D.inv0);                                       // (t_i mod p_j) * R_j
+                const u256 term = mont_mul(mont_mul(ti_m, load_u256(mat + (size_t)i * Lp + j), D.q, D.inv0), one, D.q, D.inv0);
+                acc = add_mod(acc, term, D.q);
+            }
+            store_u256(out + (b * Lp + j) * n + x, acc);
+        }
+    }
+}
+
 }  // namespace fhe_dev

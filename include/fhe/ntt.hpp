@@ -61,6 +61,10 @@ public:
     // include/ntt.cuh:114-117 (undefined in the reference): d_data is [batch][n] 256-bit integers, d_rns_data [batch][L][n]
     void to_rns(uint256_t *d_rns_data, const uint256_t *d_data, uint32_t batch = 1) { check(fhe_rns_to_rns(h_, d_rns_data, d_data, batch), "to_rns"); }
     void from_rns(uint256_t *d_data, const uint256_t *d_rns_data, uint32_t batch = 1) { check(fhe_rns_from_rns(h_, d_data, d_rns_data, batch), "from_rns"); }
+    // RNSContext::base_extend (include/rns.cuh:47-48): fast base conversion into `target`'s primes; d_out is [batch][L'][n]
+    void base_extend(uint256_t *d_out, const uint256_t *d_in, RNS_NTTEngine &target, uint32_t batch = 1) {
+        check(fhe_rns_fast_base_convert(h_, target.h_, d_out, d_in, batch), "base_extend");
+    }
     // RNSContext::mod_switch_rns (include/rns.cuh:44): drop the last prime with rounding; d_out is [batch][L-1][n]
     void rescale_drop_last(uint256_t *d_out, const uint256_t *d_in, uint32_t batch = 1) { check(fhe_rns_rescale_drop_last(h_, d_out, d_in, batch), "rescale_drop_last"); }
     void pointwise_rns(uint256_t *d_result, const uint256_t *d_a, const uint256_t *d_b, uint32_t batch = 1) {

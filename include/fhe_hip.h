@@ -152,6 +152,12 @@ int fhe_rns_from_rns(fhe_rns_ntt_t *h, void *d_values, const void *d_rns, uint32
  * d_out is [batch][L-1][n] (the layout of an engine built on the first L-1 primes).  Needs L >= 2. */
 int fhe_rns_rescale_drop_last(fhe_rns_ntt_t *h, void *d_out, const void *d_in, uint32_t batch);
 
+/* Fast base conversion (Bajard et al.) -- RNSContext::base_extend / fast_base_conversion_kernel (include/rns.cuh:47-48,
+ * 116-125, undefined in the reference): d_out[b][j][x] = sum_i [x_i (Q/q_i)^-1]_{q_i} (Q/q_i) mod p_j for the primes p_j of
+ * `target` (an engine of the same degree).  The value is that of X + alpha*Q, 0 <= alpha < L (inexact by design of the
+ * method; the computation itself is deterministic).  d_in: [batch][L][n] in src's basis, d_out: [batch][L'][n] in target's. */
+int fhe_rns_fast_base_convert(fhe_rns_ntt_t *src, fhe_rns_ntt_t *target, void *d_out, const void *d_in, uint32_t batch);
+
 /* ---- relinearisation / key switching ------------------------------------------ */
 /* RelinKeys (include/fhe.cuh:52-55) as produced by FHEContext::relinkey_gen (src/fhe.cu:76-111):
  * key pairs (b, a) with b = -a*s + e + g*s^2, one per decomposition level.  In the RNS representation every residue

@@ -572,3 +572,40 @@ void orc_rescale_drop_last(orc_plan *const *plans, uint32_t L, orc_u256 *out, co
             }
     }
 }
+
+/* ------------------------------------------------------------------------------------------ */
+void orc_fast_base_convert(orc_plan *const *src, uint32_t L, orc_plan *const *dst, uint32_t Lp, orc_u256 *out, const orc_u256 *in,
+                           uint32_t batch) {
+    const uint32_t n = src[0]->n;
+    /* (M_i^-1 mod q_i) * R_i, and for every target j: (M_i mod p_j) * R_j   with M_i = prod_{k != i} q_k taken mod the modulus at hand */
+    orc_u256 *inv_m = (orc_u256 *)malloc(L * sizeof(orc_u256)), *Mij_m = (orc_u256 *)malloc((size_t)L * Lp * sizeof(orc_u256));
+    for (uint32_t i = 0; i < L; i++) {
+        const orc_plan *p = src[i];
+        orc_u256 acc = p->r1, t, e = p->q; e.limbs[0] -= 2;
+        for (uint32_t k = 0; k < L; k++) if (k != i) { orc_u256 qk_m; orc_mont_mul(&qk_m, &src[k]->q, &p->r2, &p->q, p->inv0); orc_mont_mul(&t, &acc, &qk_m, &p->q, p->inv0); acc = t; }
+        pow_mont(p, &inv_m[i], &acc, &e);
+        for (uint32_t j = 0; j < Lp; j++) {
+            const orc_plan *d = dst[j];
+            orc_u256 a = d->r1;
+            for (uint32_t k = 0; k < L; k++) if (k != i) { orc_u256 qk_m; orc_mont_mul(&qk_m, &src[k]->q, &d->r2, &d->q, d->inv0); orc_mont_mul(&t, &a, &qk_m, &d->q, d->inv0); a = t; }
+            Mij_m[(size_t)i * Lp + j] = a;
+        }
+    }
+    for (uint32_t b = 0; b < batch; b++)
+        for (uint32_t x = 0; x < n; x++)
+            for (uint32_t j = 0; j < Lp; j++) {
+                const orc_plan *d = dst[j];
+                orc_u256 acc = u256_from(0);
+                for (uint32_t i = 0; i < L; i++) {
+                    const orc_plan *p = src[i];
+                    orc_u256 ti, ti_red, ti_m, term, s2;
+                    orc_mont_mul(&ti, &in[((size_t)b * L + i) * n + x], &inv_m[i], &p->q, p->inv0);        /* [x_i * M_i^-1]_{q_i} */
+                    orc_mont_mul(&ti_m, &ti, &d->r2, &d->q, d->inv0);                                     /* (t_i mod p_j) * R_j  */
+                    orc_mont_mul(&term, &ti_m, &Mij_m[(size_t)i * Lp + j], &d->q, d->inv0);               /* t_i * M_i * R_j      */
+                    from_mont(d, &ti_red, &term);
+                    orc_add_mod(&s2, &acc, &ti_red, &d->q); acc = s2;
+                }
+                out[((size_t)b * Lp + j) * n + x] = acc;
+            }
+    free(inv_m); free(Mij_m);
+}

@@ -122,6 +122,12 @@ int orc_from_rns(orc_plan *const *plans, uint32_t L, orc_u256 *values, const orc
  *   out[l][x] = (c[l][x] - r[x]) * q_last^-1 mod q_l,  r = the centred residue of c modulo q_last (|r| <= q_last / 2),
  * which equals (C - r) / q_last for the CRT integer C.  in: [batch][L][n], out: [batch][L-1][n]. */
 void orc_rescale_drop_last(orc_plan *const *plans, uint32_t L, orc_u256 *out, const orc_u256 *in, uint32_t batch);
+/* Fast base conversion (Bajard et al.) -- fast_base_conversion_kernel / RNSContext::base_extend (include/rns.cuh:47-48,
+ * 116-125, undefined in the reference): y[b][j][x] = sum_i [x_i * (Q/q_i)^-1]_{q_i} * (Q/q_i)  mod p_j.  The result is the
+ * residue of X + alpha*Q for the CRT integer X and some 0 <= alpha < L (the well-known inexactness of the method; the
+ * algorithm itself is deterministic, so parity is bit-exact).  src: [batch][L][n], dst: [batch][Lp][n]. */
+void orc_fast_base_convert(orc_plan *const *src, uint32_t L, orc_plan *const *dst, uint32_t Lp, orc_u256 *out, const orc_u256 *in,
+                           uint32_t batch);
 int orc_max_threads(void);
 
 #ifdef __cplusplus

@@ -74,6 +74,7 @@ def lib():
             "orc_max_threads": (ci, []),
             "orc_to_rns": (None, [ctypes.POINTER(vp), u32, P, P, u32]),
             "orc_from_rns": (ci, [ctypes.POINTER(vp), u32, P, P, u32]),
+            "orc_fast_base_convert": (None, [ctypes.POINTER(vp), u32, ctypes.POINTER(vp), u32, P, P, u32]),
             "orc_rescale_drop_last": (None, [ctypes.POINTER(vp), u32, P, P, u32]),
             "orc_relin_num_digits": (u32, [ctypes.POINTER(vp), u32, u32]),
             "orc_relinearize": (ci, [ctypes.POINTER(vp), u32, u32, P, P, P, ctypes.POINTER(P), ctypes.POINTER(P), u32, ci]),
@@ -314,6 +315,14 @@ def _rns_rescale(self, rns):
     lib().orc_rescale_drop_last(self._arr, self.L, _p(out), _p(np.ascontiguousarray(rns)), batch); return out
 
 
+def _rns_base_convert(self, target, rns):
+    """Fast base conversion of [batch][L][n] residues to the basis of `target` (another RnsPlan): [batch][L'][n]."""
+    batch = self._batch(rns); assert target.n == self.n
+    out = np.empty((batch, target.L, self.n, 4), np.uint64)
+    lib().orc_fast_base_convert(self._arr, self.L, target._arr, target.L, _p(out), _p(np.ascontiguousarray(rns)), batch); return out
+
+
+RnsPlan.fast_base_convert = _rns_base_convert
 RnsPlan.rescale_drop_last = _rns_rescale
 RnsPlan.to_rns = _rns_to_rns
 RnsPlan.from_rns = _rns_from_rns

@@ -649,3 +649,21 @@ def test_rescale_drop_last_matches_oracle(eng, oracle, n, bits, L):
     e2 = eng.RnsNttEngine(n, moduli[:-1]); e2.check_canonical(dOut, batch)
     with pytest.raises(eng.FheError):
         eng.RnsNttEngine(n, moduli[:1]).rescale_drop_last(dOut, dIn, 1)
+
+
+@pytest.mark.parametrize("n,bits,L,bits2,Lp", [(8192, 30, 4, 30, 5), (2048, 30, 3, 60, 2), (1024, 60, 2, 40, 3), (64, 120, 2, 250, 1)])
+def test_fast_base_conversion_matches_oracle(eng, oracle, n, bits, L, bits2, Lp):
+    src = nm.ntt_primes(bits, n, L)
+    dst = [p for p in nm.ntt_primes(bits2, n, Lp + L) if p not in src][:Lp]
+    e, t = eng.RnsNttEngine(n, src), eng.RnsNttEngine(n, dst)
+    S, D = oracle.RnsPlan(n, src), oracle.RnsPlan(n, dst)
+    batch = 2
+    x = rns_poly(501, src, n, batch)
+    for l, q in enumerate(src):
+        x[0, l, :2] = oracle.to_limbs([0, q - 1])
+    dX = _up(eng, x); dY = eng.DeviceBuffer(batch * Lp * n * 32)
+    e.fast_base_convert(t, dY, dX, batch)
+    assert np.array_equal(dY.download((batch, Lp, n, 4)), S.fast_base_convert(D, x))
+    t.check_canonical(dY, batch)
+    # converting to a second target re-derives the matrix
+    e.fast_base_convert(e, eng.DeviceBuffer(x.nbytes), dX, batch)

@@ -320,3 +320,25 @@ def test_rescale_drop_last_is_rounded_division(oracle, n, bits, L):
             assert (C - r) % ql == 0 and abs(want * ql - C) <= ql // 2
             for l, q in enumerate(moduli[:-1]):
                 assert oracle.from_limbs(out[b, l, i:i + 1])[0] == want % q
+
+
+@pytest.mark.parametrize("n,bits,L,bits2,Lp", [(16, 30, 3, 30, 4), (16, 30, 4, 60, 2), (8, 60, 2, 30, 3), (8, 120, 2, 250, 1)])
+def test_fast_base_conversion_matches_its_definition(oracle, n, bits, L, bits2, Lp):
+    """y_j = sum_i [x_i (Q/q_i)^-1]_{q_i} (Q/q_i) mod p_j = (X + alpha Q) mod p_j with 0 <= alpha < L."""
+    src = nm.ntt_primes(bits, n, L)
+    dst = [p for p in nm.ntt_primes(bits2, n, Lp + L) if p not in src][:Lp]
+    Q = 1
+    for q in src:
+        Q *= q
+    S, D = oracle.RnsPlan(n, src), oracle.RnsPlan(n, dst)
+    rng = random.Random(bits + bits2)
+    vals = [rng.randrange(Q) for _ in range(n - 2)] + [0, Q - 1]
+    R = S.to_rns(oracle.to_limbs(vals).reshape(1, n, 4))
+    Y = S.fast_base_convert(D, R)
+    for i, X in enumerate(vals):
+        t = [(X % q) * pow(Q // q, -1, q) % q for q in src]
+        full = sum(ti * (Q // q) for ti, q in zip(t, src))
+        alpha, rem = divmod(full - X, Q)
+        assert rem == 0 and 0 <= alpha < L
+        for j, p in enumerate(dst):
+            assert oracle.from_limbs(Y[0, j, i:i + 1])[0] == full % p
