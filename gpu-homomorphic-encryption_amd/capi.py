@@ -75,6 +75,8 @@ def lib():
         "fhe_rns_check_canonical": ([vp, vp, u32], ci),
         "fhe_rns_to_rns": ([vp, vp, vp, u32], ci),
         "fhe_rns_from_rns": ([vp, vp, vp, u32], ci),
+        "fhe_rns_monomial_mul_sub": ([vp, vp, vp, vp, u32], ci),
+        "fhe_blind_rotate_step": ([vp, vp, vp, vp, vp, vp, vp, vp, u32], ci),
         "fhe_rns_fast_base_convert": ([vp, vp, vp, vp, u32], ci),
         "fhe_rns_rescale_drop_last": ([vp, vp, vp, u32], ci),
         "fhe_relin_num_digits": ([vp, u32, P(u32)], ci),
@@ -289,6 +291,13 @@ class RnsNttEngine:
 
     def from_rns(self, d_values, d_rns, batch=1):
         _check(lib().fhe_rns_from_rns(self.h, _ptr(d_values), _ptr(d_rns), batch))
+
+    def monomial_mul_sub(self, d_out, d_in, d_shifts, batch=1):
+        _check(lib().fhe_rns_monomial_mul_sub(self.h, _ptr(d_out), _ptr(d_in), _ptr(d_shifts), batch))
+
+    def blind_rotate_step(self, rows_c0, rows_c1, d_acc0, d_acc1, d_shifts, d_tmp0, d_tmp1, batch=1):
+        _check(lib().fhe_blind_rotate_step(self.h, rows_c0.h, rows_c1.h, _ptr(d_acc0), _ptr(d_acc1), _ptr(d_shifts), _ptr(d_tmp0),
+                                           _ptr(d_tmp1), batch))
 
     def fast_base_convert(self, target, d_out, d_in, batch=1):
         _check(lib().fhe_rns_fast_base_convert(self.h, target.h, _ptr(d_out), _ptr(d_in), batch))

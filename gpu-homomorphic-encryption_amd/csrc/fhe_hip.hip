@@ -861,6 +861,39 @@ extern "C" int fhe_rns_fast_base_convert(fhe_rns_ntt_t *h, fhe_rns_ntt_t *target
     return post_launch(h->stream, "fast_base_convert_kernel");
 }
 
+
+// ------------------------------------------------------------------------------------------------------
+// blind-rotation inner loop
+// ------------------------------------------------------------------------------------------------------
+template <class F>
+static int monomial_lds(fhe_rns_ntt *h, void *out, const void *in, const uint32_t *shifts, uint32_t batch) {
+    using V = typename F::V16;
+    size_t halves = (size_t)batch * h->L * h->n * 2;
+    hipLaunchKernelGGL((fhe_dev::monomial_mul_sub_kernel<F>), dim3(ew_grid(halves)), dim3(256), 0, h->stream, (V *)out, (const V *)in, shifts,
+                       (const fhe_dev::Limb<F> *)h->d_limbs, h->L, h->log_n, halves);
+    return post_launch(h->stream, "monomial_mul_sub_kernel");
+}
+extern "C" int fhe_rns_monomial_mul_sub(fhe_rns_ntt_t *h, void *d_out, const void *d_in, const uint32_t *d_shifts, uint32_t batch) {
+    int rc = check_call(h, batch, "monomial_mul_sub"); if (rc) return rc;
+    if (!d_out || !d_in || !d_shifts || d_out == d_in) return fail(FHE_ERR_INVALID_ARG, "monomial_mul_sub: null or aliased argument");
+    if (h->width == FHE_WIDTH_32) return monomial_lds<fhe_dev::F32>(h, d_out, d_in, d_shifts, batch);
+    if (h->width == FHE_WIDTH_52) return monomial_lds<fhe_dev::F52>(h, d_out, d_in, d_shifts, batch);
+    if (h->width == FHE_WIDTH_64) return monomial_lds<fhe_dev::F64>(h, d_out, d_in, d_shifts, batch);
+    size_t count = (size_t)batch * h->L * h->n;
+    hipLaunchKernelGGL(fhe_dev::monomial_mul_sub256_kernel, dim3(ew_grid(count)), dim3(256), 0, h->stream, (fhe_dev::u256 *)d_out,
+                       (const fhe_dev::u256 *)d_in, d_shifts, (const fhe_dev::Limb256 *)h->d_limbs, h->L, h->log_n, count);
+    return post_launch(h->stream, "monomial_mul_sub256_kernel");
+}
+extern "C" int fhe_blind_rotate_step(fhe_rns_ntt_t *h, const fhe_relin_keys_t *rows_c0, const fhe_relin_keys_t *rows_c1, void *d_acc0, void *d_acc1,
+                                     const uint32_t *d_shifts, void *d_tmp0, void *d_tmp1, uint32_t batch) {
+    if (!rows_c0 || !rows_c1 || !d_tmp0 || !d_tmp1) return fail(FHE_ERR_INVALID_ARG, "blind_rotate_step: null argument");
+    int rc;
+    if ((rc = fhe_rns_monomial_mul_sub(h, d_tmp0, d_acc0, d_shifts, batch))) return rc;       // d0 = (X^a - 1) * acc0
+    if ((rc = fhe_rns_monomial_mul_sub(h, d_tmp1, d_acc1, d_shifts, batch))) return rc;       // d1 = (X^a - 1) * acc1
+    if ((rc = fhe_ct_relinearize(h, rows_c0, d_acc0, d_acc1, d_tmp0, batch))) return rc;      // acc += sum D(d0) * rows_c0
+    return fhe_ct_relinearize(h, rows_c1, d_acc0, d_acc1, d_tmp1, batch);                     // acc += sum D(d1) * rows_c1
+}
+
 // ------------------------------------------------------------------------------------------------------
 // single-modulus engine ABI = RNS engine with one limb
 // ------------------------------------------------------------------------------------------------------

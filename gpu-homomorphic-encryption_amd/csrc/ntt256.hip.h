@@ -302,4 +302,23 @@ fast_base_convert_kernel(u256 *__restrict__ out, const u256 *__restrict__ in, co
     }
 }
 
+// (X^shift[b] - 1) * p on full-width containers (see monomial_mul_sub_kernel in ntt_lds.hip.h)
+__global__ void __launch_bounds__(256)
+monomial_mul_sub256_kernel(u256 *__restrict__ out, const u256 *__restrict__ in, const uint32_t *__restrict__ shifts,
+                           const Limb256 *__restrict__ limbs, uint32_t L, uint32_t log_n, size_t count) {
+    const uint32_t n = 1u << log_n;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < count; g += stride) {
+        const size_t poly = g >> log_n;
+        const uint32_t x = (uint32_t)(g & (n - 1)), a = shifts[poly / L] & (2 * n - 1);
+        uint32_t k = (x + 2 * n - a) & (2 * n - 1);
+        const bool neg = k >= n; k &= n - 1;
+        const u256 q = limbs[(uint32_t)(poly % L)].q;
+        u256 v = load_u256(in + (poly << log_n) + k), zero;
+        zero.l[0] = zero.l[1] = zero.l[2] = zero.l[3] = 0;
+        if (neg) v = sub_mod(zero, v, q);
+        store_u256(out + g, sub_mod(v, load_u256(in + g), q));
+    }
+}
+
 }  // namespace fhe_dev

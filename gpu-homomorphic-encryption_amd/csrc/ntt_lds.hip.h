@@ -789,4 +789,31 @@ relin_mac_kernel(typename F::V16 *__restrict__ acc0, typename F::V16 *__restrict
     }
 }
 
+// ---- blind-rotation building block: out[b][l][x] = ((X^shift[b] - 1) * in[b][l])[x] over Z_q[x]/(x^n + 1), shift in [0, 2n) ----
+// (FHEContext::blind_rotate is only declared in the reference, include/fhe.cuh:139.)  One 16-byte half container per lane;
+// the rotated read is a shifted contiguous run, so it stays coalesced.
+template <class F>
+__global__ void __launch_bounds__(256)
+monomial_mul_sub_kernel(typename F::V16 *__restrict__ out, const typename F::V16 *__restrict__ in, const uint32_t *__restrict__ shifts,
+                        const Limb<F> *__restrict__ limbs, uint32_t L, uint32_t log_n, size_t halves) {
+    using E = typename F::E;
+    const uint32_t n = 1u << log_n;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < halves; g += stride) {
+        E o = 0;
+        if (!(g & 1)) {
+            const size_t c = g >> 1, poly = c >> log_n;                   // container index, polynomial index b*L + l
+            const uint32_t x = (uint32_t)(c & (n - 1));
+            const uint32_t a = shifts[poly / L] & (2 * n - 1);
+            uint32_t k = (x + 2 * n - a) & (2 * n - 1);
+            const bool neg = k >= n; k &= n - 1;
+            const E q = limbs[(uint32_t)(poly % L)].q;
+            E v = F::load_low(in + ((poly << log_n) + k) * 2);
+            if (neg) v = F::ew_sub((E)0, v, q);
+            o = F::ew_sub(v, F::load_low(in + g), q);
+        }
+        __builtin_nontemporal_store(F::pack(o), out + g);
+    }
+}
+
 }  // namespace fhe_dev

@@ -176,6 +176,19 @@ int fhe_relin_keys_destroy(fhe_relin_keys_t *rk);
  * c0, c1 are [batch][L][n] and updated in place; c2 is read only. */
 int fhe_ct_relinearize(fhe_rns_ntt_t *h, const fhe_relin_keys_t *rk, void *d_c0, void *d_c1, const void *d_c2, uint32_t batch);
 
+/* ---- blind-rotation inner loop ------------------------------------------------------ */
+/* FHEContext::blind_rotate is only declared in the reference (include/fhe.cuh:139; pipeline prose README.md:146-159).  Its
+ * inner loop is  acc <- acc + ExternalProduct((X^a - 1) * acc, RGSW(s)),  and the external product of an RLWE pair (d0, d1)
+ * with an RGSW ciphertext is two key switches accumulated into one pair.  An RGSW ciphertext is therefore imported as two
+ * fhe_relin_keys_t objects (rows for component 0 and for component 1, level order j*K + k as for relinearisation keys).
+ *
+ * d_out[b][l] = (X^shift[b] - 1) * d_in[b][l] over Z_q[x]/(x^n + 1); d_shifts is a DEVICE array of `batch` values in [0, 2n). */
+int fhe_rns_monomial_mul_sub(fhe_rns_ntt_t *h, void *d_out, const void *d_in, const uint32_t *d_shifts, uint32_t batch);
+/* One blind-rotation step for `batch` independent accumulators: (acc0, acc1) += ExtProd((X^a - 1) * (acc0, acc1), RGSW) with
+ * per-accumulator shifts.  d_tmp0 / d_tmp1 are caller-provided scratch polynomials ([batch][L][n] each). */
+int fhe_blind_rotate_step(fhe_rns_ntt_t *h, const fhe_relin_keys_t *rows_c0, const fhe_relin_keys_t *rows_c1, void *d_acc0, void *d_acc1,
+                          const uint32_t *d_shifts, void *d_tmp0, void *d_tmp1, uint32_t batch);
+
 /* Scan a [batch][L][n] buffer for coefficients that are not canonical (>= q_limb, or non-zero
  * upper limbs on the narrow paths).  Synchronises.  FHE_OK or FHE_ERR_NONCANONICAL. */
 int fhe_rns_check_canonical(fhe_rns_ntt_t *h, const void *d_data, uint32_t batch);

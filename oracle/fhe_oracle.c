@@ -609,3 +609,24 @@ void orc_fast_base_convert(orc_plan *const *src, uint32_t L, orc_plan *const *ds
             }
     free(inv_m); free(Mij_m);
 }
+
+/* ------------------------------------------------------------------------------------------ */
+void orc_monomial_mul_sub(orc_plan *const *plans, uint32_t L, orc_u256 *out, const orc_u256 *in, const uint32_t *shifts, uint32_t batch) {
+    const uint32_t n = plans[0]->n;
+    for (uint32_t b = 0; b < batch; b++) {
+        const uint32_t a = shifts[b] % (2 * n);
+        for (uint32_t l = 0; l < L; l++) {
+            const orc_plan *p = plans[l];
+            const orc_u256 *src = in + ((size_t)b * L + l) * n;
+            orc_u256 *dst = out + ((size_t)b * L + l) * n;
+            for (uint32_t x = 0; x < n; x++) {
+                /* coefficient x of X^a * p: +-p[(x - a) mod 2n folded into n] */
+                uint32_t k = (x + 2 * n - a) % (2 * n);
+                int neg = k >= n; if (neg) k -= n;
+                orc_u256 zero = u256_from(0), v = src[k], t;
+                if (neg) { orc_sub_mod(&t, &zero, &v, &p->q); v = t; }
+                orc_sub_mod(&dst[x], &v, &src[x], &p->q);
+            }
+        }
+    }
+}

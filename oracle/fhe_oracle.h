@@ -128,6 +128,13 @@ void orc_rescale_drop_last(orc_plan *const *plans, uint32_t L, orc_u256 *out, co
  * algorithm itself is deterministic, so parity is bit-exact).  src: [batch][L][n], dst: [batch][Lp][n]. */
 void orc_fast_base_convert(orc_plan *const *src, uint32_t L, orc_plan *const *dst, uint32_t Lp, orc_u256 *out, const orc_u256 *in,
                            uint32_t batch);
+/* Blind-rotation building block -- FHEContext::blind_rotate (include/fhe.cuh:139) is declared only; README.md:146-159
+ * names the step ("evaluate a function on encrypted data using a test vector").  Its inner loop is
+ *   acc <- acc + ExternalProduct((X^a - 1) * acc, RGSW(s))
+ * where the external product of an RLWE pair (d0, d1) with an RGSW ciphertext is two key switches accumulated into one
+ * pair (orc_relinearize with c2 := d0 and the rows for component 0, then c2 := d1 with the rows for component 1).
+ * This function is the remaining piece: out[b][l][x] = ((X^shift[b] - 1) * in[b][l])[x] over Z_q[x]/(x^n + 1), shift in [0, 2n). */
+void orc_monomial_mul_sub(orc_plan *const *plans, uint32_t L, orc_u256 *out, const orc_u256 *in, const uint32_t *shifts, uint32_t batch);
 int orc_max_threads(void);
 
 #ifdef __cplusplus

@@ -74,6 +74,7 @@ def lib():
             "orc_max_threads": (ci, []),
             "orc_to_rns": (None, [ctypes.POINTER(vp), u32, P, P, u32]),
             "orc_from_rns": (ci, [ctypes.POINTER(vp), u32, P, P, u32]),
+            "orc_monomial_mul_sub": (None, [ctypes.POINTER(vp), u32, P, P, ctypes.POINTER(u32), u32]),
             "orc_fast_base_convert": (None, [ctypes.POINTER(vp), u32, ctypes.POINTER(vp), u32, P, P, u32]),
             "orc_rescale_drop_last": (None, [ctypes.POINTER(vp), u32, P, P, u32]),
             "orc_relin_num_digits": (u32, [ctypes.POINTER(vp), u32, u32]),
@@ -322,6 +323,23 @@ def _rns_base_convert(self, target, rns):
     lib().orc_fast_base_convert(self._arr, self.L, target._arr, target.L, _p(out), _p(np.ascontiguousarray(rns)), batch); return out
 
 
+def _rns_monomial_mul_sub(self, rns, shifts):
+    """(X^shift[b] - 1) * p for every polynomial of ciphertext b."""
+    batch = self._batch(rns); sh = np.ascontiguousarray(shifts, dtype=np.uint32); assert sh.size == batch
+    out = np.empty_like(rns)
+    lib().orc_monomial_mul_sub(self._arr, self.L, _p(out), _p(np.ascontiguousarray(rns)), sh.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), batch)
+    return out
+
+
+def _rns_blind_rotate_step(self, decomp_bits, acc0, acc1, shifts, rows0, rows1, threads=1):
+    """acc + ExternalProduct((X^a - 1) * acc, RGSW): rows0 / rows1 = (keys_b, keys_a) for the digits of component 0 / 1."""
+    d0 = self.monomial_mul_sub(acc0, shifts); d1 = self.monomial_mul_sub(acc1, shifts)
+    o0, o1 = self.relinearize(decomp_bits, acc0, acc1, d0, rows0[0], rows0[1], threads)
+    return self.relinearize(decomp_bits, o0, o1, d1, rows1[0], rows1[1], threads)
+
+
+RnsPlan.monomial_mul_sub = _rns_monomial_mul_sub
+RnsPlan.blind_rotate_step = _rns_blind_rotate_step
 RnsPlan.fast_base_convert = _rns_base_convert
 RnsPlan.rescale_drop_last = _rns_rescale
 RnsPlan.to_rns = _rns_to_rns

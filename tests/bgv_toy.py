@@ -98,6 +98,25 @@ class ToyBGV:
                 keys_b.append(b); keys_a.append(a)
         return keys_b, keys_a, K
 
+    def rgsw(self, mu, decomp_bits):
+        """RGSW encryption of the small integer mu as two row sets (one per RLWE component), each a pair of key lists in the
+        relinearisation-key layout: rows0[jk] = RLWE(0) + (g_jk * mu, 0), rows1[jk] = RLWE(0) + (0, g_jk * mu)."""
+        K = (max(q.bit_length() for q in self.moduli) + decomp_bits - 1) // decomp_bits
+        s_r = self.to_rns(self.s)
+        out = []
+        for comp in (0, 1):
+            kb, ka = [], []
+            for j in range(self.L):
+                for k in range(K):
+                    a = self.uniform(); e = self.small()
+                    b = self.sub(self.to_rns([self.t * ei for ei in e]), self.mul(a, s_r))      # RLWE(0): b + a*s = t*e
+                    g = pow(2, k * decomp_bits, self.moduli[j]) * mu % self.moduli[j]
+                    tgt = b if comp == 0 else a
+                    tgt[j] = [(tgt[j][0] + g) % self.moduli[j]] + tgt[j][1:]                     # + g * mu on the constant coefficient
+                    kb.append(b); ka.append(a)
+            out.append((kb, ka))
+        return out[0], out[1], K
+
     # ---- slot (batch) encoding: t = 1 (mod 2n) ---------------------------------------------------------
     def _slot_matrix(self):
         """V[i][j] = zeta_i^j mod t at the n odd powers zeta_i = psi^(2i+1) (int64 is enough: t < 2^31)."""

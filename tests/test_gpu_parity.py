@@ -667,3 +667,67 @@ def test_fast_base_conversion_matches_oracle(eng, oracle, n, bits, L, bits2, Lp)
     t.check_canonical(dY, batch)
     # converting to a second target re-derives the matrix
     e.fast_base_convert(e, eng.DeviceBuffer(x.nbytes), dX, batch)
+
+
+# ------------------------------------------------------------------------------------ N3: blind-rotation inner loop
+@pytest.mark.parametrize("n,spec,w,batch", [(8192, ("bits", 30, 4), 16, 5), (4096, ("bits", 40, 2), 20, 3), (2048, ("bits", 60, 1), 32, 2),
+                                            (256, ("bits", 250, 1), 64, 2)])
+def test_blind_rotate_step_matches_oracle(eng, oracle, n, spec, w, batch):
+    moduli = _moduli(spec, n); L = len(moduli)
+    e = eng.RnsNttEngine(n, moduli); rp = oracle.RnsPlan(n, moduli)
+    K = e.relin_num_digits(w)
+    rows = [(_random_keys(moduli, n, L * K, 7000 + 100 * c), _random_keys(moduli, n, L * K, 8000 + 100 * c)) for c in range(2)]
+    imported = [e.import_relin_keys(w, [_up(eng, k) for k in kb], [_up(eng, k) for k in ka]) for kb, ka in rows]
+    a0, a1 = rns_poly(601, moduli, n, batch), rns_poly(602, moduli, n, batch)
+    shifts = np.array([0, 1, n - 1, n, 2 * n - 1, 12345 % (2 * n)][:batch] + [7] * max(0, batch - 6), dtype=np.uint32)[:batch]
+    dSh = eng.DeviceBuffer.from_numpy(shifts)
+    # the monomial kernel alone
+    dT = eng.DeviceBuffer(a0.nbytes); dA0, dA1 = _up(eng, a0), _up(eng, a1)
+    e.monomial_mul_sub(dT, dA0, dSh, batch)
+    assert np.array_equal(dT.download(a0.shape), rp.monomial_mul_sub(a0, shifts))
+    # two full steps
+    dT1 = eng.DeviceBuffer(a0.nbytes)
+    w0, w1 = a0, a1
+    for _ in range(2):
+        e.blind_rotate_step(imported[0], imported[1], dA0, dA1, dSh, dT, dT1, batch)
+        w0, w1 = rp.blind_rotate_step(w, w0, w1, shifts, rows[0], rows[1], threads=8)
+    assert np.array_equal(dA0.download(a0.shape), w0) and np.array_equal(dA1.download(a0.shape), w1)
+
+
+def test_blind_rotation_rotates_the_plaintext_on_gpu(eng, oracle):
+    """Three blind-rotation steps with secret bits 1, 0, 1 (toy BGV on the host, N = 2048): the decrypted accumulator is
+    X^(sum a_i s_i) * m."""
+    import bgv_toy
+    n, t, w = 2048, 12289, 16                                  # t = 1 (mod 2n) is not needed here: coefficient encoding
+    moduli = eng.find_ntt_primes(30, n, 2)
+    rp = oracle.RnsPlan(n, moduli)
+
+    def fast_mul(x, y):
+        return bgv_toy.from_limb_array(rp.polymul(bgv_toy.to_limb_array(x), bgv_toy.to_limb_array(y), threads=8))
+
+    S = bgv_toy.ToyBGV(n, moduli, t, seed=21, fast_mul=fast_mul)
+    rng = random.Random(8)
+    m = [rng.randrange(t) for _ in range(n)]
+    c0, c1 = S.encrypt(m)
+    e = eng.RnsNttEngine(n, moduli)
+    dA0, dA1 = _up(eng, bgv_toy.to_limb_array(c0)), _up(eng, bgv_toy.to_limb_array(c1))
+    dT0, dT1 = eng.DeviceBuffer(dA0.nbytes), eng.DeviceBuffer(dA0.nbytes)
+    total = 0
+    for bit, a in ((1, 100), (0, 999), (1, n + 77)):
+        r0, r1, K = S.rgsw(bit, w)
+        imp = [e.import_relin_keys(w, [_up(eng, bgv_toy.to_limb_array(k)[0]) for k in r[0]], [_up(eng, bgv_toy.to_limb_array(k)[0]) for k in r[1]])
+               for r in (r0, r1)]
+        dSh = eng.DeviceBuffer.from_numpy(np.array([a], dtype=np.uint32))
+        e.blind_rotate_step(imp[0], imp[1], dA0, dA1, dSh, dT0, dT1, 1)
+        total += a * bit
+    shape = (1, 2, n, 4)
+    got = S.decrypt([bgv_toy.from_limb_array(dA0.download(shape)), bgv_toy.from_limb_array(dA1.download(shape))])
+    k = total % (2 * n)
+    want = [0] * n
+    for i, mi in enumerate(m):                                  # X^k * m, negacyclic
+        j = i + k
+        sign = 1
+        while j >= n:
+            j -= n; sign = -sign
+        want[j] = (sign * mi) % t
+    assert got == want

@@ -342,3 +342,43 @@ def test_fast_base_conversion_matches_its_definition(oracle, n, bits, L, bits2, 
         assert rem == 0 and 0 <= alpha < L
         for j, p in enumerate(dst):
             assert oracle.from_limbs(Y[0, j, i:i + 1])[0] == full % p
+
+
+# ---------------------------------------------------------------------------------- N3: blind-rotation inner loop
+def test_monomial_mul_sub_matches_definition(oracle):
+    n = 32; moduli = nm.ntt_primes(30, n, 2); rp = oracle.RnsPlan(n, moduli)
+    from workload import rns_poly
+    x = rns_poly(5, moduli, n, 4)
+    shifts = [0, 1, n + 3, 2 * n - 1]
+    out = rp.monomial_mul_sub(x, shifts)
+    for b, a in enumerate(shifts):
+        mono = [0] * n
+        sign = 1 if a < n else -1
+        mono[a % n] = sign
+        for l, q in enumerate(moduli):
+            p = [int(v) for v in x[b, l, :, 0]]
+            want = [(u - v) % q for u, v in zip(nm.negacyclic_mul_direct([m % q for m in mono], p, q), p)]
+            assert [int(v) for v in out[b, l, :, 0]] == want
+
+
+def test_blind_rotate_steps_rotate_the_plaintext(oracle):
+    """acc <- acc + ExtProd((X^a - 1) acc, RGSW(s)) multiplies the encrypted polynomial by X^(a*s): three steps with
+    secret bits 1, 0, 1 (toy BGV, big-integer decryption)."""
+    import bgv_toy
+    n, t, w = 64, 257, 16
+    moduli = nm.ntt_primes(30, n, 2)
+    S = bgv_toy.ToyBGV(n, moduli, t, seed=9)
+    rp = oracle.RnsPlan(n, moduli)
+    rng = random.Random(3)
+    m = [rng.randrange(t) for _ in range(n)]
+    c0, c1 = S.encrypt(m)
+    A0, A1 = bgv_toy.to_limb_array(c0), bgv_toy.to_limb_array(c1)
+    total = 0
+    for bit, a in ((1, 5), (0, 17), (1, n + 9)):
+        r0, r1, K = S.rgsw(bit, w)
+        rows = [tuple([bgv_toy.to_limb_array(k)[0] for k in part] for part in r) for r in (r0, r1)]
+        A0, A1 = rp.blind_rotate_step(w, A0, A1, [a], rows[0], rows[1])
+        total += a * bit
+        mono = [0] * n; mono[total % n] = 1 if (total // n) % 2 == 0 else t - 1
+        want = nm.negacyclic_mul_direct(mono, m, t)
+        assert S.decrypt([bgv_toy.from_limb_array(A0), bgv_toy.from_limb_array(A1)]) == want
