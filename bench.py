@@ -43,10 +43,13 @@ def parse():
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL over xGMI) on a multi-GPU node; gloo only to rehearse the N > 1 path on a one-GPU box")
     ap.add_argument("--device-override", type=int, default=None, help="rehearsal only: put every rank on this device")
-    ap.add_argument("--op", choices=["multiply", "fwdinv", "ct", "relin", "ctrelin"], default="multiply",
+    ap.add_argument("--op", choices=["multiply", "fwdinv", "ct", "relin", "ctrelin", "blindrotate"], default="multiply",
                     help="multiply = fused polymul (the headline, configs[1]); fwdinv = forward+inverse NTT pair; "
                          "ct = ciphertext tensor product; relin = key switching of c2 into (c0, c1); "
-                         "ctrelin = tensor product + relinearisation (configs[2]: full ciphertext multiply)")
+                         "ctrelin = tensor product + relinearisation (configs[2]: full ciphertext multiply); "
+                         "blindrotate = blind-rotation inner loop (configs[4]): --br-steps external products per accumulator and step")
+    ap.add_argument("--br-steps", type=int, default=8, help="blindrotate: external products per bench step (one fhe_blind_rotate call)")
+    ap.add_argument("--br-keys", type=int, default=4, help="blindrotate: distinct RGSW ciphertexts cycled through by the loop")
     ap.add_argument("--decomp-bits", type=int, default=16, help="relinearisation digit width w (reference default 16)")
     ap.add_argument("--extras", action="store_true", help="also time forward+inverse pairs")
     return ap.parse_args()
@@ -131,7 +134,7 @@ def main():
     moduli = pkg.find_ntt_primes(args.bits, n, L)
     eng = pkg.RnsNttEngine(n, moduli)
     S = 32 * n * L                                   # bytes of one RNS polynomial
-    n_in, n_out = {"multiply": (2, 1), "fwdinv": (1, 0), "ct": (4, 3), "relin": (3, 0), "ctrelin": (4, 3)}[args.op]
+    n_in, n_out = {"multiply": (2, 1), "fwdinv": (1, 0), "ct": (4, 3), "relin": (3, 0), "ctrelin": (4, 3), "blindrotate": (2, 2)}[args.op]
     ins = [pkg.DeviceBuffer(B * S) for _ in range(n_in)]
     outs = [pkg.DeviceBuffer(B * S) for _ in range(n_out)]
     for i, buf in enumerate(ins):
@@ -152,6 +155,28 @@ def main():
         step = lambda: eng.ct_multiply(outs[0], outs[1], outs[2], ins[0], ins[1], ins[2], ins[3], B)
         unit, units_per_poly_bytes, kernel = "ct-mul/s", 7, "ntt_ct_multiply_kernel"
         what = "ciphertext tensor product c0=a0b0, c1=a0b1+a1b0, c2=a1b1 (no relinearisation)"
+    elif args.op == "blindrotate":
+        import numpy as np
+        from workload import rns_poly
+        K = eng.relin_num_digits(args.decomp_bits)
+        rgsw = []
+        for g in range(args.br_keys):            # RGSW ciphertext g = two row sets of L*K key pairs each (synthetic uniform residues)
+            rows = []
+            for c in range(2):
+                keys = [[pkg.DeviceBuffer.from_numpy(rns_poly(9000 + 31 * i + 997 * h + 5000 * c + 20000 * g, moduli, n, 1)) for i in range(L * K)]
+                        for h in range(2)]
+                rows.append(eng.import_relin_keys(args.decomp_bits, keys[0], keys[1]))
+                del keys
+            rgsw.append(rows)
+        R = args.br_steps
+        rows0 = [rgsw[s % args.br_keys][0] for s in range(R)]; rows1 = [rgsw[s % args.br_keys][1] for s in range(R)]
+        shifts = np.random.default_rng(1234 + rank).integers(0, 2 * n, size=(R, B), dtype=np.uint32)
+        dSh = pkg.DeviceBuffer.from_numpy(shifts)
+        step = lambda: eng.blind_rotate(rows0, rows1, ins[0], ins[1], dSh, outs[0], outs[1], B)
+        # per external product: read the accumulator pair, write the accumulator pair (keys are shared by the whole batch)
+        unit, units_per_poly_bytes, kernel = "extprod/s", 4 * R, "ntt_extprod_kernel"
+        what = (f"blind-rotation inner loop: {R} steps acc += ExtProd((X^a - 1) acc, RGSW_s) per accumulator, w = {args.decomp_bits}, "
+                f"{2 * L * K} rows per RGSW, {args.br_keys} RGSW keys cycled")
     else:
         from workload import rns_poly
         K = eng.relin_num_digits(args.decomp_bits)
@@ -195,7 +220,8 @@ def main():
 
     wall, ev_ms = timed(step, args.steps, args.warmup)
     ms_per_step = wall * 1e3 / args.steps
-    value = B * world / (wall / args.steps)
+    units_per_step = B * (args.br_steps if args.op == "blindrotate" else 1)      # units one rank processes per step
+    value = units_per_step * world / (wall / args.steps)
     launch_ms = ev_ms / args.steps                   # HIP-event time of one step's launches on the engine stream
     algo_bytes = units_per_poly_bytes * S * B        # 3*S per polymul, 4*S per fwd+inv pair, 7*S per ct-mul (+5*S relin)
     achieved = algo_bytes / (launch_ms * 1e-3) / 1e9

@@ -77,6 +77,7 @@ def lib():
         "fhe_rns_from_rns": ([vp, vp, vp, u32], ci),
         "fhe_rns_monomial_mul_sub": ([vp, vp, vp, vp, u32], ci),
         "fhe_blind_rotate_step": ([vp, vp, vp, vp, vp, vp, vp, vp, u32], ci),
+        "fhe_blind_rotate": ([vp, P(vp), P(vp), u32, vp, vp, vp, vp, vp, u32], ci),
         "fhe_rns_fast_base_convert": ([vp, vp, vp, vp, u32], ci),
         "fhe_rns_rescale_drop_last": ([vp, vp, vp, u32], ci),
         "fhe_relin_num_digits": ([vp, u32, P(u32)], ci),
@@ -298,6 +299,13 @@ class RnsNttEngine:
     def blind_rotate_step(self, rows_c0, rows_c1, d_acc0, d_acc1, d_shifts, d_tmp0, d_tmp1, batch=1):
         _check(lib().fhe_blind_rotate_step(self.h, rows_c0.h, rows_c1.h, _ptr(d_acc0), _ptr(d_acc1), _ptr(d_shifts), _ptr(d_tmp0),
                                            _ptr(d_tmp1), batch))
+
+    def blind_rotate(self, rows_c0, rows_c1, d_acc0, d_acc1, d_shifts, d_tmp0, d_tmp1, batch=1):
+        """rows_c0 / rows_c1: one imported row set per step (lists of equal length); d_shifts: device uint32 [steps][batch]."""
+        steps = len(rows_c0); assert len(rows_c1) == steps
+        arr = ctypes.c_void_p * max(steps, 1)
+        a0 = arr(*[r.h for r in rows_c0]); a1 = arr(*[r.h for r in rows_c1])
+        _check(lib().fhe_blind_rotate(self.h, a0, a1, steps, _ptr(d_acc0), _ptr(d_acc1), _ptr(d_shifts), _ptr(d_tmp0), _ptr(d_tmp1), batch))
 
     def fast_base_convert(self, target, d_out, d_in, batch=1):
         _check(lib().fhe_rns_fast_base_convert(self.h, target.h, _ptr(d_out), _ptr(d_in), batch))

@@ -8,6 +8,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "host_math.hpp"
@@ -671,7 +672,14 @@ extern "C" int fhe_relin_keys_create(fhe_rns_ntt_t *h, fhe_relin_keys_t **out, u
         fhe_host::u128 digit_bound = decomp_bits >= 64 ? q_max : (((fhe_host::u128)1 << decomp_bits) < q_max ? ((fhe_host::u128)1 << decomp_bits) : q_max);
         digits_fit = digit_bound <= 4 * q_min;
     }
-    if (!rc && h->width != FHE_WIDTH_256 && digits_fit && !getenv("FHE_HIP_NO_FUSED_KEYSWITCH")) rc = pack_relin_keys(h, rk);
+    if (!rc && h->width != FHE_WIDTH_256 && digits_fit && !getenv("FHE_HIP_NO_FUSED_KEYSWITCH")) {
+        rc = pack_relin_keys(h, rk);
+        if (!rc) {   // the fused kernels read only the packed tables (n * sizeof(E) bytes per key polynomial instead of n * 32): drop the
+                     // container copy, so that a bootstrapping key of several hundred RGSW ciphertexts fits (hipFree waits for the packing)
+            (void)hipFree(rk->d_kb); (void)hipFree(rk->d_ka);
+            rk->d_kb = rk->d_ka = nullptr;
+        }
+    }
     if (rc) { fhe_relin_keys_destroy(rk); return rc; }
     *out = rk;
     return FHE_OK;
@@ -720,6 +728,7 @@ extern "C" int fhe_ct_relinearize(fhe_rns_ntt_t *h, const fhe_relin_keys_t *rk, 
         if (!fn) return fail(FHE_ERR_UNSUPPORTED, "transform size outside the LDS-resident range");
         fhe_dev::LdsArgs A{fhe_dev::LDS_KEYSWITCH, d_c0, d_c1, nullptr, d_c2, nullptr, nullptr, nullptr, h->d_limbs, h->L, batch * h->L, h->stream};
         A.kb = rk->d_pkb; A.ka = rk->d_pka; A.K = rk->K; A.w = rk->decomp_bits;
+        A.global_twiddles = getenv("FHE_HIP_NO_LDS_TWIDDLES") != nullptr;
         fn(A);
         return post_launch(h->stream, "ntt_keyswitch_kernel");
     }
@@ -884,14 +893,67 @@ extern "C" int fhe_rns_monomial_mul_sub(fhe_rns_ntt_t *h, void *d_out, const voi
                        (const fhe_dev::u256 *)d_in, d_shifts, (const fhe_dev::Limb256 *)h->d_limbs, h->L, h->log_n, count);
     return post_launch(h->stream, "monomial_mul_sub256_kernel");
 }
-extern "C" int fhe_blind_rotate_step(fhe_rns_ntt_t *h, const fhe_relin_keys_t *rows_c0, const fhe_relin_keys_t *rows_c1, void *d_acc0, void *d_acc1,
+// One step on the general composition (any width class): d = (X^a - 1) * acc, then two key switches accumulate into acc in place.
+static int blind_rotate_step_general(fhe_rns_ntt_t *h, const fhe_relin_keys_t *rows_c0, const fhe_relin_keys_t *rows_c1, void *d_acc0, void *d_acc1,
                                      const uint32_t *d_shifts, void *d_tmp0, void *d_tmp1, uint32_t batch) {
-    if (!rows_c0 || !rows_c1 || !d_tmp0 || !d_tmp1) return fail(FHE_ERR_INVALID_ARG, "blind_rotate_step: null argument");
     int rc;
     if ((rc = fhe_rns_monomial_mul_sub(h, d_tmp0, d_acc0, d_shifts, batch))) return rc;       // d0 = (X^a - 1) * acc0
     if ((rc = fhe_rns_monomial_mul_sub(h, d_tmp1, d_acc1, d_shifts, batch))) return rc;       // d1 = (X^a - 1) * acc1
     if ((rc = fhe_ct_relinearize(h, rows_c0, d_acc0, d_acc1, d_tmp0, batch))) return rc;      // acc += sum D(d0) * rows_c0
     return fhe_ct_relinearize(h, rows_c1, d_acc0, d_acc1, d_tmp1, batch);                     // acc += sum D(d1) * rows_c1
+}
+// One step as ONE launch (word-sized classes with packed rows): (out0, out1) = (in0, in1) + ExtProd((X^a - 1) * in, RGSW).
+static int blind_rotate_step_fused(fhe_rns_ntt_t *h, const fhe_relin_keys_t *r0, const fhe_relin_keys_t *r1, void *out0, void *out1, const void *in0,
+                                   const void *in1, const uint32_t *d_shifts, uint32_t batch) {
+    fhe_dev::lds_launch_fn fn = fhe_dev::lds_lookup(h->width == FHE_WIDTH_32 ? 32 : h->width == FHE_WIDTH_52 ? 52 : 64, (int)h->log_n);
+    if (!fn) return fail(FHE_ERR_UNSUPPORTED, "transform size outside the LDS-resident range");
+    fhe_dev::LdsArgs A{fhe_dev::LDS_EXTPROD, out0, out1, nullptr, in0, in1, nullptr, nullptr, h->d_limbs, h->L, batch * h->L, h->stream};
+    A.kb = r0->d_pkb; A.ka = r0->d_pka; A.kb1 = r1->d_pkb; A.ka1 = r1->d_pka; A.K = r0->K; A.w = r0->decomp_bits; A.shifts = d_shifts;
+    A.global_twiddles = getenv("FHE_HIP_NO_LDS_TWIDDLES") != nullptr;
+    fn(A);
+    return post_launch(h->stream, "ntt_extprod_kernel");
+}
+static int check_rows(const fhe_rns_ntt_t *h, const fhe_relin_keys_t *r0, const fhe_relin_keys_t *r1) {
+    if (!r0 || !r1) return fail(FHE_ERR_INVALID_ARG, "blind_rotate: null RGSW rows");
+    if (r0->owner != h || r1->owner != h) return fail(FHE_ERR_INVALID_ARG, "blind_rotate: rows were imported for a different engine");
+    if (r0->decomp_bits != r1->decomp_bits || r0->K != r1->K) return fail(FHE_ERR_INVALID_ARG, "blind_rotate: the two row sets use different digit widths");
+    return FHE_OK;
+}
+extern "C" int fhe_blind_rotate(fhe_rns_ntt_t *h, const fhe_relin_keys_t *const *rows_c0, const fhe_relin_keys_t *const *rows_c1, uint32_t steps,
+                                void *d_acc0, void *d_acc1, const uint32_t *d_shifts, void *d_tmp0, void *d_tmp1, uint32_t batch) {
+    int rc = check_call(h, batch, "blind_rotate"); if (rc) return rc;
+    if (!d_acc0 || !d_acc1 || !d_tmp0 || !d_tmp1 || !d_shifts || (steps && (!rows_c0 || !rows_c1))) return fail(FHE_ERR_INVALID_ARG, "blind_rotate: null argument");
+    {   // the four buffers must be pairwise distinct
+        const void *bufs[4] = {d_acc0, d_acc1, d_tmp0, d_tmp1};
+        for (int x = 0; x < 4; x++) for (int y = x + 1; y < 4; y++)
+            if (bufs[x] == bufs[y]) return fail(FHE_ERR_INVALID_ARG, "blind_rotate: accumulators and scratch must be distinct buffers");
+    }
+    bool fused = h->width != FHE_WIDTH_256 && !getenv("FHE_HIP_NO_FUSED_BLIND_ROTATE");
+    for (uint32_t s = 0; s < steps; s++) {
+        if ((rc = check_rows(h, rows_c0[s], rows_c1[s]))) return rc;
+        fused = fused && rows_c0[s]->d_pkb && rows_c1[s]->d_pkb;
+    }
+    if (!fused) {
+        for (uint32_t s = 0; s < steps; s++)
+            if ((rc = blind_rotate_step_general(h, rows_c0[s], rows_c1[s], d_acc0, d_acc1, d_shifts + (size_t)s * batch, d_tmp0, d_tmp1, batch))) return rc;
+        return FHE_OK;
+    }
+    // ping-pong between (acc0, acc1) and (tmp0, tmp1): one launch per step, 4*S bytes of HBM traffic per accumulator and step
+    void *cur0 = d_acc0, *cur1 = d_acc1, *nxt0 = d_tmp0, *nxt1 = d_tmp1;
+    for (uint32_t s = 0; s < steps; s++) {
+        if ((rc = blind_rotate_step_fused(h, rows_c0[s], rows_c1[s], nxt0, nxt1, cur0, cur1, d_shifts + (size_t)s * batch, batch))) return rc;
+        std::swap(cur0, nxt0); std::swap(cur1, nxt1);
+    }
+    if (cur0 != d_acc0) {   // odd number of steps: the result sits in the scratch pair
+        const size_t bytes = (size_t)batch * h->L * h->n * 32;
+        HIP_TRY(hipMemcpyAsync(d_acc0, cur0, bytes, hipMemcpyDeviceToDevice, h->stream));
+        HIP_TRY(hipMemcpyAsync(d_acc1, cur1, bytes, hipMemcpyDeviceToDevice, h->stream));
+    }
+    return FHE_OK;
+}
+extern "C" int fhe_blind_rotate_step(fhe_rns_ntt_t *h, const fhe_relin_keys_t *rows_c0, const fhe_relin_keys_t *rows_c1, void *d_acc0, void *d_acc1,
+                                     const uint32_t *d_shifts, void *d_tmp0, void *d_tmp1, uint32_t batch) {
+    return fhe_blind_rotate(h, &rows_c0, &rows_c1, 1, d_acc0, d_acc1, d_shifts, d_tmp0, d_tmp1, batch);
 }
 
 // ------------------------------------------------------------------------------------------------------

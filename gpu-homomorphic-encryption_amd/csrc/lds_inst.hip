@@ -39,15 +39,43 @@ void CAT(lds_launch_, FHE_FIELD, FHE_LOGN)(const LdsArgs &A) {
                                    (const char *)A.b1, (const char *)A.a1, (const char *)A.b0, limbs, A.L);
             }
             break;
-        case LDS_KEYSWITCH:
-            if constexpr (lds_keyswitch_split(sizeof(typename F::E), LOGN)) {
+        case LDS_KEYSWITCH: {
+            using E = typename F::E;
+            if constexpr (lds_keyswitch_split(sizeof(E), LOGN)) {
                 hipLaunchKernelGGL((ntt_keyswitch_kernel<F, LOGN, 2, true>), dim3(A.polys * 2), block, 0, A.stream, (char *)A.r0, (char *)A.r1,
-                                   (const char *)A.a0, (const typename F::E *)A.kb, (const typename F::E *)A.ka, limbs, A.L, A.K, A.w);
+                                   (const char *)A.a0, (const E *)A.kb, (const E *)A.ka, limbs, A.L, A.K, A.w);
             } else {
-                hipLaunchKernelGGL((ntt_keyswitch_kernel<F, LOGN, 2, false>), grid, block, 0, A.stream, (char *)A.r0, (char *)A.r1,
-                                   (const char *)A.a0, (const typename F::E *)A.kb, (const typename F::E *)A.ka, limbs, A.L, A.K, A.w);
+                if (lds_twiddles_in_lds(sizeof(E), LOGN) && !A.global_twiddles) {
+                    if constexpr (lds_twiddles_in_lds(sizeof(E), LOGN))
+                        hipLaunchKernelGGL((ntt_keyswitch_kernel<F, LOGN, 2, false, true>), grid, block, 0, A.stream, (char *)A.r0, (char *)A.r1,
+                                           (const char *)A.a0, (const E *)A.kb, (const E *)A.ka, limbs, A.L, A.K, A.w);
+                } else {
+                    hipLaunchKernelGGL((ntt_keyswitch_kernel<F, LOGN, 2, false>), grid, block, 0, A.stream, (char *)A.r0, (char *)A.r1,
+                                       (const char *)A.a0, (const E *)A.kb, (const E *)A.ka, limbs, A.L, A.K, A.w);
+                }
             }
             break;
+        }
+        case LDS_EXTPROD: {
+            using E = typename F::E;
+            if constexpr (lds_keyswitch_split(sizeof(E), LOGN)) {
+                hipLaunchKernelGGL((ntt_extprod_kernel<F, LOGN, 2, true>), dim3(A.polys * 2), block, 0, A.stream, (char *)A.r0, (char *)A.r1,
+                                   (const char *)A.a0, (const char *)A.a1, A.shifts, (const E *)A.kb, (const E *)A.ka, (const E *)A.kb1,
+                                   (const E *)A.ka1, limbs, A.L, A.K, A.w);
+            } else {
+                if (lds_twiddles_in_lds(sizeof(E), LOGN) && !A.global_twiddles) {
+                    if constexpr (lds_twiddles_in_lds(sizeof(E), LOGN))
+                        hipLaunchKernelGGL((ntt_extprod_kernel<F, LOGN, 2, false, true>), grid, block, 0, A.stream, (char *)A.r0, (char *)A.r1,
+                                           (const char *)A.a0, (const char *)A.a1, A.shifts, (const E *)A.kb, (const E *)A.ka, (const E *)A.kb1,
+                                           (const E *)A.ka1, limbs, A.L, A.K, A.w);
+                } else {
+                    hipLaunchKernelGGL((ntt_extprod_kernel<F, LOGN, 2, false>), grid, block, 0, A.stream, (char *)A.r0, (char *)A.r1,
+                                       (const char *)A.a0, (const char *)A.a1, A.shifts, (const E *)A.kb, (const E *)A.ka, (const E *)A.kb1,
+                                       (const E *)A.ka1, limbs, A.L, A.K, A.w);
+                }
+            }
+            break;
+        }
     }
 }
 

@@ -6,7 +6,7 @@
 
 namespace fhe_dev {
 
-enum LdsOp { LDS_FORWARD = 0, LDS_INVERSE = 1, LDS_MULTIPLY = 2, LDS_CT_MULTIPLY = 3, LDS_KEYSWITCH = 4 };
+enum LdsOp { LDS_FORWARD = 0, LDS_INVERSE = 1, LDS_MULTIPLY = 2, LDS_CT_MULTIPLY = 3, LDS_KEYSWITCH = 4, LDS_EXTPROD = 5 };
 
 // true when the instance runs the tensor product as one fused launch; otherwise LDS_CT_MULTIPLY issues
 // multiply(c0), multiply(c2) and the two-product kernel for c1 (three launches, 11*S instead of 7*S bytes)
@@ -14,6 +14,12 @@ constexpr bool lds_ct_fused(int elem_bytes, int log_n) { return elem_bytes == 4 
 // key switching: 4-byte residues run one workgroup per (ciphertext, limb); 8-byte residues and 1024-thread blocks (N = 2^15)
 // two, one per key half (three live arrays instead of four)
 constexpr bool lds_keyswitch_split(int elem_bytes, int log_n) { return elem_bytes == 8 || log_n >= 15; }
+
+// key switching / external product in the one-workgroup-per-limb form: twiddle tables copied into LDS for 4-byte residues up
+// to N = 2^13 (exchange buffer + table = 65 KiB per workgroup, still two workgroups per CU).  Interleaved A/B on one MI355X
+// (scripts/bench_ab_twiddles.sh): external product N = 8192 +7 %, relinearisation N = 8192 +-0 %; at N = 2^14 (130 KiB, one
+// workgroup per CU) it was 1-6 % slower, so that size keeps reading twiddles through L2.
+constexpr bool lds_twiddles_in_lds(int elem_bytes, int log_n) { return elem_bytes == 4 && log_n <= 13; }
 
 struct LdsArgs {
     int op;
@@ -24,6 +30,11 @@ struct LdsArgs {
     hipStream_t stream;
     const void *kb = nullptr, *ka = nullptr;   // LDS_KEYSWITCH: packed key tables (r0 = c0, r1 = c1, a0 = c2)
     uint32_t K = 0, w = 0;
+    // LDS_EXTPROD (fused blind-rotation step): r0, r1 = out pair, a0, a1 = in pair, kb / ka = rows of component 0,
+    // kb1 / ka1 = rows of component 1, shifts = device array of per-ciphertext monomial exponents
+    const void *kb1 = nullptr, *ka1 = nullptr;
+    const uint32_t *shifts = nullptr;
+    bool global_twiddles = false;        // testing aid (FHE_HIP_NO_LDS_TWIDDLES=1): run the variant that reads twiddles from L2
 };
 
 typedef void (*lds_launch_fn)(const LdsArgs &);

@@ -245,6 +245,8 @@ template <int LOGN> struct PatA {
     using C = NttCfg<LOGN>;
     static constexpr int BIT0 = C::LOGT;
     static constexpr bool TW_UNIFORM = true;      // every stage on these bits has i >> (b+1) independent of tid
+    static constexpr uint32_t TW_STRIDE = 0;
+    __device__ static uint32_t tw_thread(uint32_t) { return 0; }
     __device__ static uint32_t base(uint32_t tid) { return tid; }
     __device__ static uint32_t pbase(uint32_t tid) { return tid + (tid >> 5); }
     static constexpr uint32_t off(int r) { return (uint32_t)r << C::LOGT; }
@@ -255,6 +257,8 @@ template <int LOGN> struct PatM {
     using C = NttCfg<LOGN>;
     static constexpr int BIT0 = C::REM;
     static constexpr bool TW_UNIFORM = false;
+    static constexpr uint32_t TW_STRIDE = 32;                                 // distinct twiddle-owning thread groups (T >> REM)
+    __device__ static uint32_t tw_thread(uint32_t tid) { return tid >> C::REM; }
     __device__ static uint32_t base(uint32_t tid) { return ((tid >> C::REM) << (C::REM + 5)) | (tid & ((1u << C::REM) - 1)); }
     __device__ static uint32_t pbase(uint32_t tid) { uint32_t b = base(tid); return b + (b >> 5); }
     static constexpr uint32_t off(int r) { return (uint32_t)r << C::REM; }
@@ -264,6 +268,8 @@ template <int LOGN> struct PatM {
 template <int LOGN> struct PatZ {
     static constexpr int BIT0 = 0;
     static constexpr bool TW_UNIFORM = false;
+    static constexpr uint32_t TW_STRIDE = NttCfg<LOGN>::T;
+    __device__ static uint32_t tw_thread(uint32_t tid) { return tid; }
     __device__ static uint32_t base(uint32_t tid) { return tid << 5; }
     __device__ static uint32_t pbase(uint32_t tid) { return tid * 33; }
     static constexpr uint32_t off(int r) { return (uint32_t)r; }
@@ -273,6 +279,8 @@ template <int LOGN> struct PatZ {
 template <int LOGN> struct PatY {
     static constexpr int BIT0 = 5;
     static constexpr bool TW_UNIFORM = false;
+    static constexpr uint32_t TW_STRIDE = NttCfg<LOGN>::T / 32;
+    __device__ static uint32_t tw_thread(uint32_t tid) { return tid >> 5; }
     __device__ static uint32_t base(uint32_t tid) { return ((tid >> 5) << 10) | (tid & 31); }
     __device__ static uint32_t pbase(uint32_t tid) { return (tid >> 5) * 1056 + (tid & 31); }
     static constexpr uint32_t off(int r) { return (uint32_t)r << 5; }
@@ -292,37 +300,76 @@ __device__ __forceinline__ void lds_get(const E *lds, uint32_t tid, E (&x)[32]) 
     for (int r = 0; r < 32; r++) x[r] = p[Pat::poff(r)];
 }
 
+// ---- twiddle tables ----------------------------------------------------------------------------------------
+// The stage on index bit b uses w[m + (i >> (b+1))], m = N >> (b+1), i = coefficient index.  In device memory the tables are
+// in that natural order (a wave's strided walk re-uses the lines its first load brought into L1; a lane-consecutive order was
+// measured 5-10 % SLOWER there).  Kernels that run many transforms under one modulus (key switching, external product) copy
+// the table into LDS instead, PERMUTED within each stage range so that the lanes of a wave read consecutive words (no bank
+// conflicts): for a stage that runs as r-bit k of pattern Pat, j = i >> (b+1) = tt << (4-k) | rh with tt = Pat::tw_thread(tid)
+// and rh = r >> (k+1); the entry sits at slot m + rh * Pat::TW_STRIDE + tt.  Forward tables use patterns Z / M, inverse
+// tables Z / Y; the stages of the uniform pattern A (m <= 16) always take scalar loads from device memory.
+template <class Pat>
+__device__ __host__ constexpr uint32_t tw_slot_off(int r, int k) { return (uint32_t)(r >> (k + 1)) * Pat::TW_STRIDE; }
+// LDS slot of natural index idx in [1, n) of the forward (fwd = true) or inverse table for n = 2^log_n
+__device__ __host__ inline uint32_t tw_slot(uint32_t log_n, bool fwd, uint32_t idx) {
+    const uint32_t lg = 31 - (uint32_t)__builtin_clz(idx);
+    const uint32_t m = 1u << lg, j = idx - m, b = log_n - 1 - lg, rem = log_n - 10, T = 1u << (log_n - 5);
+    uint32_t k, stride;
+    if (fwd) {
+        if (b < rem) { k = b; stride = T; }                       // pattern Z
+        else if (b < rem + 5) { k = b - rem; stride = 32; }       // pattern M
+        else return idx;                                          // pattern A (never read from LDS)
+    } else {
+        if (b < 5) { k = b; stride = T; }                         // pattern Z
+        else if (b < 10) { k = b - 5; stride = T / 32; }          // pattern Y
+        else return idx;
+    }
+    const uint32_t sh = 4 - k, tt = j >> sh, rh = j & ((1u << sh) - 1);
+    return m + rh * stride + tt;
+}
+// Copy a table into LDS in the permuted order (coalesced reads; the scattered LDS writes happen once per workgroup and table).
+template <class F, int LOGN, bool FWD>
+__device__ __forceinline__ void stage_twiddles(typename F::TW *twl, const typename F::TW *__restrict__ gtw, uint32_t tid) {
+    using C = NttCfg<LOGN>;
+#pragma unroll 8
+    for (uint32_t idx = tid; idx < (uint32_t)C::N; idx += C::T)
+        if (idx >= 1) twl[tw_slot(LOGN, FWD, idx)] = gtw[idx];     // entry 0 is unused; pattern-A entries keep their natural slot
+}
+
 // ---- register-resident butterfly stages -------------------------------------------------------------
 // Forward (Cooley-Tukey, merged psi twiddles): stage on index bit b uses twiddle tw[m + (i >> (b+1))], m = N >> (b+1).
 // Processes r-bits KHI down to KLO of pattern Pat.  Values stay in [0, 4q).
-template <class F, int LOGN, class Pat, int KHI, int KLO>
+// TWL: `tw` is an LDS copy in the permuted order (non-uniform patterns only).
+template <class F, int LOGN, class Pat, int KHI, int KLO, bool TWL = false>
 __device__ __forceinline__ void fwd_stages(typename F::E (&x)[32], uint32_t tid, const typename F::TW *__restrict__ tw, const Limb<F> &P) {
-    const uint32_t base = Pat::TW_UNIFORM ? 0u : Pat::base(tid);   // uniform -> scalar twiddle loads
+    static_assert(!(TWL && Pat::TW_UNIFORM), "uniform stages read device memory");
+    const uint32_t base = TWL ? Pat::tw_thread(tid) : Pat::TW_UNIFORM ? 0u : Pat::base(tid);   // uniform -> scalar twiddle loads
 #pragma unroll
     for (int k = KHI; k >= KLO; k--) {
         const int b = Pat::BIT0 + k;
-        const typename F::TW *p = tw + ((1u << (LOGN - 1 - b)) + (base >> (b + 1)));
+        const typename F::TW *p = tw + ((1u << (LOGN - 1 - b)) + (TWL ? base : (base >> (b + 1))));
 #pragma unroll
         for (int r = 0; r < 32; r++) {
             if (r & (1 << k)) continue;
-            const typename F::TW w = p[Pat::off(r) >> (b + 1)];
+            const typename F::TW w = p[TWL ? tw_slot_off<Pat>(r, k) : (Pat::off(r) >> (b + 1))];
             F::fwd_bfly(x[r], x[r | (1 << k)], w, P);
         }
     }
 }
 // Inverse (Gentleman-Sande): stage on index bit b uses itw[m + (i >> (b+1))].  Processes r-bits KLO up to KHI.
 // Values stay in [0, 2q).
-template <class F, int LOGN, class Pat, int KLO, int KHI>
+template <class F, int LOGN, class Pat, int KLO, int KHI, bool TWL = false>
 __device__ __forceinline__ void inv_stages(typename F::E (&x)[32], uint32_t tid, const typename F::TW *__restrict__ itw, const Limb<F> &P) {
-    const uint32_t base = Pat::TW_UNIFORM ? 0u : Pat::base(tid);
+    static_assert(!(TWL && Pat::TW_UNIFORM), "uniform stages read device memory");
+    const uint32_t base = TWL ? Pat::tw_thread(tid) : Pat::TW_UNIFORM ? 0u : Pat::base(tid);
 #pragma unroll
     for (int k = KLO; k <= KHI; k++) {
         const int b = Pat::BIT0 + k;
-        const typename F::TW *p = itw + ((1u << (LOGN - 1 - b)) + (base >> (b + 1)));
+        const typename F::TW *p = itw + ((1u << (LOGN - 1 - b)) + (TWL ? base : (base >> (b + 1))));
 #pragma unroll
         for (int r = 0; r < 32; r++) {
             if (r & (1 << k)) continue;
-            const typename F::TW w = p[Pat::off(r) >> (b + 1)];
+            const typename F::TW w = p[TWL ? tw_slot_off<Pat>(r, k) : (Pat::off(r) >> (b + 1))];
             F::inv_bfly(x[r], x[r | (1 << k)], w, P);
         }
     }
@@ -362,30 +409,35 @@ __device__ __forceinline__ void store_from_lds(char *__restrict__ poly, const ty
 
 // ---- whole-transform building blocks (data in registers, lds = workgroup scratch) ----------------------
 // natural-order coefficients in pattern A  ->  NTT values in pattern Z, in [0, 4q)
-template <class F, int LOGN>
-__device__ __forceinline__ void fwd_core(typename F::E (&x)[32], typename F::E *lds, uint32_t tid, const Limb<F> &P) {
+// TWL: the non-uniform stages take their twiddles from `twl`, an LDS copy made by stage_twiddles<F, LOGN, true>.
+template <class F, int LOGN, bool TWL = false>
+__device__ __forceinline__ void fwd_core(typename F::E (&x)[32], typename F::E *lds, uint32_t tid, const Limb<F> &P,
+                                         const typename F::TW *twl = nullptr) {
     using C = NttCfg<LOGN>;
+    const typename F::TW *t2 = TWL ? twl : P.tw;
     fwd_stages<F, LOGN, PatA<LOGN>, 4, 0>(x, tid, P.tw, P);
     lds_put<PatA<LOGN>>(lds, tid, x);
     __syncthreads();
     lds_get<PatM<LOGN>>(lds, tid, x);
-    fwd_stages<F, LOGN, PatM<LOGN>, 4, 0>(x, tid, P.tw, P);
+    fwd_stages<F, LOGN, PatM<LOGN>, 4, 0, TWL>(x, tid, t2, P);
     lds_put<PatM<LOGN>>(lds, tid, x);          // same slots this thread just read: no barrier needed before
     __syncthreads();
     lds_get<PatZ<LOGN>>(lds, tid, x);
-    fwd_stages<F, LOGN, PatZ<LOGN>, C::REM - 1, 0>(x, tid, P.tw, P);
+    fwd_stages<F, LOGN, PatZ<LOGN>, C::REM - 1, 0, TWL>(x, tid, t2, P);
 }
 // NTT values in pattern Z, in [0, 2q)  ->  coefficients in pattern A, in [0, 2q), scaled by the (ninv..) constants
-template <class F, int LOGN>
+template <class F, int LOGN, bool TWL = false>
 __device__ __forceinline__ void inv_core(typename F::E (&x)[32], typename F::E *lds, uint32_t tid, const Limb<F> &P,
-                                         typename F::E ninv, typename F::E ninv_s, typename F::E ninvw, typename F::E ninvw_s) {
+                                         typename F::E ninv, typename F::E ninv_s, typename F::E ninvw, typename F::E ninvw_s,
+                                         const typename F::TW *twl = nullptr) {
     using C = NttCfg<LOGN>;
-    inv_stages<F, LOGN, PatZ<LOGN>, 0, 4>(x, tid, P.itw, P);
+    const typename F::TW *t2 = TWL ? twl : P.itw;
+    inv_stages<F, LOGN, PatZ<LOGN>, 0, 4, TWL>(x, tid, t2, P);
     F::regroup(x, P.q, P.qinv);
     lds_put<PatZ<LOGN>>(lds, tid, x);
     __syncthreads();
     lds_get<PatY<LOGN>>(lds, tid, x);
-    inv_stages<F, LOGN, PatY<LOGN>, 0, 4>(x, tid, P.itw, P);
+    inv_stages<F, LOGN, PatY<LOGN>, 0, 4, TWL>(x, tid, t2, P);
     F::regroup(x, P.q, P.qinv);
     lds_put<PatY<LOGN>>(lds, tid, x);
     __syncthreads();
@@ -636,7 +688,10 @@ pack_keys_kernel(typename F::E *__restrict__ packed, const typename F::V16 *__re
 // SPLIT = true : two workgroups per (b, i), one per key half (3 live arrays; 8-byte residues, whose four arrays would not fit the
 //                register file); the digit transforms are then computed twice, which is still far cheaper than the general
 //                composition's container-sized digit workspace.
-template <class F, int LOGN, int MINW = 1, bool SPLIT = false>
+// TWL = true: the forward (then the inverse) twiddle table of limb i is copied into LDS once per workgroup; the 2*L*K + 2
+// transforms then take their non-uniform twiddles from LDS (~100 cycles, conflict-free in the permuted order) instead of L2
+// (500+ cycles), which these register-starved kernels (2 waves per SIMD) cannot hide.  N * sizeof(TW) more LDS per workgroup.
+template <class F, int LOGN, int MINW = 1, bool SPLIT = false, bool TWL = false>
 __global__ void __launch_bounds__(NttCfg<LOGN>::T, MINW)
 ntt_keyswitch_kernel(char *__restrict__ c0, char *__restrict__ c1, const char *__restrict__ c2,
                      const typename F::E *__restrict__ kb, const typename F::E *__restrict__ ka,
@@ -645,7 +700,9 @@ ntt_keyswitch_kernel(char *__restrict__ c0, char *__restrict__ c1, const char *_
     using E = typename F::E;
     constexpr int VPL = 16 / sizeof(E), NCH = 32 / VPL;
     typedef E VecE __attribute__((ext_vector_type(VPL)));
+    static_assert(!(TWL && SPLIT), "LDS twiddles are wired into the one-workgroup-per-limb form only");
     __shared__ E lds[C::LDS_ELEMS];
+    __shared__ typename F::TW twl[TWL ? C::N : 1];
     // XCD-aware workgroup -> (ciphertext, limb[, half]) map: workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8
     // names the L2 a workgroup shares), and the workgroups of one ciphertext all re-read the same c2, so they are given block
     // indices that are congruent mod 8 and close together: the re-reads then hit one XCD's L2 instead of crossing the
@@ -663,12 +720,13 @@ ntt_keyswitch_kernel(char *__restrict__ c0, char *__restrict__ c1, const char *_
         E acc0[32], acc1[32], x[32], d[32];
 #pragma unroll
         for (int r = 0; r < 32; r++) { acc0[r] = 0; acc1[r] = 0; }
+        if constexpr (TWL) { stage_twiddles<F, LOGN, true>(twl, P.tw, tid); __syncthreads(); }
         for (uint32_t j = 0; j < L; j++) {
             load_A<F, LOGN>(c2 + ((size_t)b * L + j) * (C::N * 32), tid, x);
             for (uint32_t k = 0; k < K; k++) {
 #pragma unroll
                 for (int r = 0; r < 32; r++) d[r] = F::digit(x[r], k * w, w);
-                fwd_core<F, LOGN>(d, lds, tid, P);
+                fwd_core<F, LOGN, TWL>(d, lds, tid, P, twl);
                 const size_t tbl = ((size_t)(j * K + k) * L + i) * C::N;
                 const VecE *pb = reinterpret_cast<const VecE *>(kb + tbl) + tid, *pa = reinterpret_cast<const VecE *>(ka + tbl) + tid;
 #pragma unroll
@@ -684,8 +742,9 @@ ntt_keyswitch_kernel(char *__restrict__ c0, char *__restrict__ c1, const char *_
                 __syncthreads();                      // every Z-pattern read is done before the next digit's exchange
             }
         }
-        // acc0 -> coefficient domain, + c0
-        inv_core<F, LOGN>(acc0, lds, tid, P, P.ninv, P.ninv_s, P.ninvw, P.ninvw_s);
+        // acc0 -> coefficient domain, + c0   (the last forward transform ended with a barrier: the table can be swapped)
+        if constexpr (TWL) { stage_twiddles<F, LOGN, false>(twl, P.itw, tid); __syncthreads(); }
+        inv_core<F, LOGN, TWL>(acc0, lds, tid, P, P.ninv, P.ninv_s, P.ninvw, P.ninvw_s, twl);
         load_A<F, LOGN>(c0 + (size_t)p * (C::N * 32), tid, x);
 #pragma unroll
         for (int r = 0; r < 32; r++) acc0[r] = F::ew_add(F::canon_inv(acc0[r], P.q), x[r], P.q);
@@ -693,7 +752,7 @@ ntt_keyswitch_kernel(char *__restrict__ c0, char *__restrict__ c1, const char *_
         __syncthreads();
         store_from_lds<F, LOGN>(c0 + (size_t)p * (C::N * 32), lds, tid);
         __syncthreads();
-        inv_core<F, LOGN>(acc1, lds, tid, P, P.ninv, P.ninv_s, P.ninvw, P.ninvw_s);
+        inv_core<F, LOGN, TWL>(acc1, lds, tid, P, P.ninv, P.ninv_s, P.ninvw, P.ninvw_s, twl);
         load_A<F, LOGN>(c1 + (size_t)p * (C::N * 32), tid, x);
 #pragma unroll
         for (int r = 0; r < 32; r++) acc1[r] = F::ew_add(F::canon_inv(acc1[r], P.q), x[r], P.q);
@@ -735,6 +794,146 @@ ntt_keyswitch_kernel(char *__restrict__ c0, char *__restrict__ c1, const char *_
         lds_put<PatA<LOGN>>(lds, tid, acc);
         __syncthreads();
         store_from_lds<F, LOGN>(dst + (size_t)p * (C::N * 32), lds, tid);
+    }
+}
+
+// ---- fused blind-rotation step (external product) ------------------------------------------------------------------------
+// out = in + ExtProd((X^a - 1) * in, RGSW)  for the RLWE pair in = (in0, in1), OUT OF PLACE (workgroup (b, i) reads every limb of
+// in and writes limb i of out, so out must not alias in).  (FHEContext::blind_rotate is declared only, include/fhe.cuh:139.)
+//   out0[i] = in0[i] + INTT_i( sum_{c in {0,1}} sum_{j,k} NTT_i(digit_k(((X^a - 1) * in_c)[j])) .* KB_c[jk][i] ),  out1 likewise with KA_c
+// The monomial factor is applied while loading: coefficient x of (X^a - 1) * p is +-p[(x - a) mod n] - p[x]; the limb is loaded once
+// (coalesced, pattern A), parked in the exchange buffer and read back rotated, so HBM and the texture path see one read per limb.
+// 2*L*K forward + 2 inverse transforms per workgroup; HBM traffic per ciphertext: read in0, in1 (re-reads by the L workgroups of a
+// ciphertext are XCD-L2 / Infinity-Cache hits, same block map as the key-switch kernel) + write out0, out1 = 4 * S.
+// SPLIT as for the key-switch kernel: two workgroups per (b, i), one per output component.
+template <class F, int LOGN>
+__device__ __forceinline__ void load_monomial_A(const char *__restrict__ poly, typename F::E *lds, uint32_t tid, uint32_t a, typename F::E qj,
+                                                typename F::E (&x)[32]) {
+    using C = NttCfg<LOGN>;
+    using E = typename F::E;
+    load_A<F, LOGN>(poly, tid, x);                  // p[i], i = tid + r*T
+    lds_put<PatA<LOGN>>(lds, tid, x);               // the caller guarantees that nobody still reads the exchange buffer
+    __syncthreads();
+    const uint32_t k0 = tid + 2 * C::N - a;
+#pragma unroll
+    for (int r = 0; r < 32; r++) {
+        uint32_t k = (k0 + (uint32_t)r * C::T) & (2 * C::N - 1);      // (i - a) mod 2n
+        const bool neg = k >= (uint32_t)C::N;                         // X^n = -1
+        k &= C::N - 1;
+        E v = lds[k + (k >> 5)];                                      // consecutive lanes, consecutive slots: conflict-free like pattern A
+        if (neg) v = F::ew_sub((E)0, v, qj);
+        x[r] = F::ew_sub(v, x[r], qj);
+    }
+    __syncthreads();                                // rotated reads are done before the first transform reuses the buffer
+}
+
+template <class F, int LOGN, int MINW = 1, bool SPLIT = false, bool TWL = false>
+__global__ void __launch_bounds__(NttCfg<LOGN>::T, MINW)
+ntt_extprod_kernel(char *__restrict__ out0, char *__restrict__ out1, const char *__restrict__ in0, const char *__restrict__ in1,
+                   const uint32_t *__restrict__ shifts,
+                   const typename F::E *__restrict__ kb0, const typename F::E *__restrict__ ka0,      // rows for component 0
+                   const typename F::E *__restrict__ kb1, const typename F::E *__restrict__ ka1,      // rows for component 1
+                   const Limb<F> *__restrict__ limbs, uint32_t L, uint32_t K, uint32_t w) {
+    using C = NttCfg<LOGN>;
+    using E = typename F::E;
+    constexpr int VPL = 16 / sizeof(E), NCH = 32 / VPL;
+    typedef E VecE __attribute__((ext_vector_type(VPL)));
+    static_assert(!(TWL && SPLIT), "LDS twiddles are wired into the one-workgroup-per-limb form only");
+    __shared__ E lds[C::LDS_ELEMS];
+    __shared__ typename F::TW twl[TWL ? C::N : 1];
+    constexpr uint32_t H = SPLIT ? 2 : 1;
+    const uint32_t LH = L * H;
+    const uint32_t tid = threadIdx.x, bid = blockIdx.x, full = (gridDim.x / (8 * LH)) * (8 * LH);
+    uint32_t b, u;
+    if (bid < full) { const uint32_t s = bid >> 3; b = (bid & 7) + 8 * (s / LH); u = s % LH; }
+    else { b = bid / LH; u = bid % LH; }
+    const uint32_t i = u / H, half = u % H;
+    const uint32_t p = b * L + i;
+    const Limb<F> P = limbs[i];
+    const uint32_t a = shifts[b] & (2 * C::N - 1);
+    if constexpr (!SPLIT) {
+        E acc0[32], acc1[32], x[32], d[32];
+#pragma unroll
+        for (int r = 0; r < 32; r++) { acc0[r] = 0; acc1[r] = 0; }
+        if constexpr (TWL) stage_twiddles<F, LOGN, true>(twl, P.tw, tid);     // visible after the barrier inside load_monomial_A
+        for (uint32_t c = 0; c < 2; c++) {
+            const char *src = c ? in1 : in0;
+            const E *kb = c ? kb1 : kb0, *ka = c ? ka1 : ka0;
+            for (uint32_t j = 0; j < L; j++) {
+                load_monomial_A<F, LOGN>(src + ((size_t)b * L + j) * (C::N * 32), lds, tid, a, limbs[j].q, x);
+                for (uint32_t k = 0; k < K; k++) {
+#pragma unroll
+                    for (int r = 0; r < 32; r++) d[r] = F::digit(x[r], k * w, w);
+                    fwd_core<F, LOGN, TWL>(d, lds, tid, P, twl);
+                    const size_t tbl = ((size_t)(j * K + k) * L + i) * C::N;
+                    const VecE *pb = reinterpret_cast<const VecE *>(kb + tbl) + tid, *pa = reinterpret_cast<const VecE *>(ka + tbl) + tid;
+#pragma unroll
+                    for (int ch = 0; ch < NCH; ch++) {
+                        const VecE vb = pb[ch * C::T], va = pa[ch * C::T];
+#pragma unroll
+                        for (int e = 0; e < VPL; e++) {
+                            const int r = ch * VPL + e;
+                            acc0[r] = F::pw_add(acc0[r], F::pw_mul(vb[e], d[r], P.q, P.qinv), P.q, P.q2);
+                            acc1[r] = F::pw_add(acc1[r], F::pw_mul(va[e], d[r], P.q, P.qinv), P.q, P.q2);
+                        }
+                    }
+                    __syncthreads();
+                }
+            }
+        }
+        if constexpr (TWL) { stage_twiddles<F, LOGN, false>(twl, P.itw, tid); __syncthreads(); }
+        inv_core<F, LOGN, TWL>(acc0, lds, tid, P, P.ninv, P.ninv_s, P.ninvw, P.ninvw_s, twl);
+        load_A<F, LOGN>(in0 + (size_t)p * (C::N * 32), tid, x);
+#pragma unroll
+        for (int r = 0; r < 32; r++) acc0[r] = F::ew_add(F::canon_inv(acc0[r], P.q), x[r], P.q);
+        lds_put<PatA<LOGN>>(lds, tid, acc0);
+        __syncthreads();
+        store_from_lds<F, LOGN>(out0 + (size_t)p * (C::N * 32), lds, tid);
+        __syncthreads();
+        inv_core<F, LOGN, TWL>(acc1, lds, tid, P, P.ninv, P.ninv_s, P.ninvw, P.ninvw_s, twl);
+        load_A<F, LOGN>(in1 + (size_t)p * (C::N * 32), tid, x);
+#pragma unroll
+        for (int r = 0; r < 32; r++) acc1[r] = F::ew_add(F::canon_inv(acc1[r], P.q), x[r], P.q);
+        lds_put<PatA<LOGN>>(lds, tid, acc1);
+        __syncthreads();
+        store_from_lds<F, LOGN>(out1 + (size_t)p * (C::N * 32), lds, tid);
+    } else {
+        E acc[32], d[32];
+#pragma unroll
+        for (int r = 0; r < 32; r++) acc[r] = 0;
+        for (uint32_t c = 0; c < 2; c++) {
+            const char *src = c ? in1 : in0;
+            const E *keys = c ? (half ? ka1 : kb1) : (half ? ka0 : kb0);
+            for (uint32_t j = 0; j < L; j++) {
+                const E qj = limbs[j].q;
+                for (uint32_t k = 0; k < K; k++) {
+                    load_monomial_A<F, LOGN>(src + ((size_t)b * L + j) * (C::N * 32), lds, tid, a, qj, d);
+#pragma unroll
+                    for (int r = 0; r < 32; r++) d[r] = F::digit(d[r], k * w, w);
+                    fwd_core<F, LOGN>(d, lds, tid, P);
+                    __builtin_amdgcn_sched_barrier(0);
+                    const VecE *pk = reinterpret_cast<const VecE *>(keys + ((size_t)(j * K + k) * L + i) * C::N) + tid;
+#pragma unroll
+                    for (int ch = 0; ch < NCH; ch++) {
+                        const VecE v = pk[ch * C::T];
+#pragma unroll
+                        for (int e = 0; e < VPL; e++) {
+                            const int r = ch * VPL + e;
+                            acc[r] = F::pw_add(acc[r], F::pw_mul(v[e], d[r], P.q, P.qinv), P.q, P.q2);
+                        }
+                    }
+                    __syncthreads();
+                }
+            }
+            F::regroup(acc, P.q, P.qinv);          // floating-point sums of L*K products: back below q (no-op for the integer fields)
+        }
+        inv_core<F, LOGN>(acc, lds, tid, P, P.ninv, P.ninv_s, P.ninvw, P.ninvw_s);
+        load_A<F, LOGN>((half ? in1 : in0) + (size_t)p * (C::N * 32), tid, d);
+#pragma unroll
+        for (int r = 0; r < 32; r++) acc[r] = F::ew_add(F::canon_inv(acc[r], P.q), d[r], P.q);
+        lds_put<PatA<LOGN>>(lds, tid, acc);
+        __syncthreads();
+        store_from_lds<F, LOGN>((half ? out1 : out0) + (size_t)p * (C::N * 32), lds, tid);
     }
 }
 

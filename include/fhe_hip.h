@@ -185,9 +185,17 @@ int fhe_ct_relinearize(fhe_rns_ntt_t *h, const fhe_relin_keys_t *rk, void *d_c0,
  * d_out[b][l] = (X^shift[b] - 1) * d_in[b][l] over Z_q[x]/(x^n + 1); d_shifts is a DEVICE array of `batch` values in [0, 2n). */
 int fhe_rns_monomial_mul_sub(fhe_rns_ntt_t *h, void *d_out, const void *d_in, const uint32_t *d_shifts, uint32_t batch);
 /* One blind-rotation step for `batch` independent accumulators: (acc0, acc1) += ExtProd((X^a - 1) * (acc0, acc1), RGSW) with
- * per-accumulator shifts.  d_tmp0 / d_tmp1 are caller-provided scratch polynomials ([batch][L][n] each). */
+ * per-accumulator shifts.  d_tmp0 / d_tmp1 are caller-provided scratch polynomials ([batch][L][n] each, distinct from the
+ * accumulators).  Same as fhe_blind_rotate with steps = 1. */
 int fhe_blind_rotate_step(fhe_rns_ntt_t *h, const fhe_relin_keys_t *rows_c0, const fhe_relin_keys_t *rows_c1, void *d_acc0, void *d_acc1,
                           const uint32_t *d_shifts, void *d_tmp0, void *d_tmp1, uint32_t batch);
+/* The loop itself: for s = 0 .. steps-1:  acc <- acc + ExtProd((X^shift[s][b] - 1) * acc, RGSW_s), RGSW_s = (rows_c0[s], rows_c1[s]);
+ * d_shifts is a DEVICE array [steps][batch].  On the word-sized width classes every step is ONE kernel launch that reads the
+ * accumulator pair and writes the other buffer pair (ping-pong between acc and tmp; the result always ends in d_acc0 / d_acc1),
+ * 4 * S bytes of HBM traffic per accumulator and step; the full-width class composes the monomial kernel and two key switches.
+ * Nothing is allocated on the word-sized path, so the whole loop can be captured into a hipGraph. */
+int fhe_blind_rotate(fhe_rns_ntt_t *h, const fhe_relin_keys_t *const *rows_c0, const fhe_relin_keys_t *const *rows_c1, uint32_t steps,
+                     void *d_acc0, void *d_acc1, const uint32_t *d_shifts, void *d_tmp0, void *d_tmp1, uint32_t batch);
 
 /* Scan a [batch][L][n] buffer for coefficients that are not canonical (>= q_limb, or non-zero
  * upper limbs on the narrow paths).  Synchronises.  FHE_OK or FHE_ERR_NONCANONICAL. */

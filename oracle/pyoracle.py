@@ -338,7 +338,15 @@ def _rns_blind_rotate_step(self, decomp_bits, acc0, acc1, shifts, rows0, rows1, 
     return self.relinearize(decomp_bits, o0, o1, d1, rows1[0], rows1[1], threads)
 
 
+def _rns_blind_rotate(self, decomp_bits, acc0, acc1, shifts, rows0_list, rows1_list, threads=1):
+    """The loop: shifts is [steps][batch]; rows*_list hold one RGSW row set per step."""
+    for sh, r0, r1 in zip(np.asarray(shifts, dtype=np.uint32), rows0_list, rows1_list):
+        acc0, acc1 = self.blind_rotate_step(decomp_bits, acc0, acc1, sh, r0, r1, threads)
+    return acc0, acc1
+
+
 RnsPlan.monomial_mul_sub = _rns_monomial_mul_sub
+RnsPlan.blind_rotate = _rns_blind_rotate
 RnsPlan.blind_rotate_step = _rns_blind_rotate_step
 RnsPlan.fast_base_convert = _rns_base_convert
 RnsPlan.rescale_drop_last = _rns_rescale

@@ -1,0 +1,15 @@
+#!/bin/bash
+# VGPR / spill / occupancy report of the LDS-resident kernel instances (device-only compile with resource remarks).
+# usage: scripts/kernel_resources.sh "F32 13" "F52 14" ... [FILTER=regex on kernel names]
+cd "$(dirname "$0")/../gpu-homomorphic-encryption_amd/csrc" || exit 1
+OUT=$(mktemp -d)
+for i in "$@"; do set -- $i
+  (/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 --cuda-device-only -DFHE_FIELD=$1 -DFHE_LOGN=$2 \
+     -Rpass-analysis=kernel-resource-usage -c -o $OUT/x_$1_$2.o lds_inst.hip 2>&1 |
+   grep -E "Function Name|    VGPRs:|VGPRs Spill|Occupancy" | paste - - - - |
+   sed 's/\[-Rpass[^]]*\]//g; s/[^ ]*ntt_lds.hip.h:[0-9:]* //g; s/remark: //g; s/Function Name: _ZN7fhe_dev[0-9]*//; s/INS_\(F[0-9]*\)ELi\([0-9]*\)\([A-Za-z0-9]*\)EEv[^ \t]*/ \1 \2 \3/' |
+   grep -E "${FILTER:-.}" > $OUT/res_$1_$2.txt) &
+done
+wait
+cat $OUT/res_*.txt
+rm -rf $OUT

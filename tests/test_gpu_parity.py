@@ -694,6 +694,49 @@ def test_blind_rotate_step_matches_oracle(eng, oracle, n, spec, w, batch):
     assert np.array_equal(dA0.download(a0.shape), w0) and np.array_equal(dA1.download(a0.shape), w1)
 
 
+@pytest.mark.parametrize("n,spec,w,batch,steps", [(8192, ("bits", 30, 4), 16, 9, 3), (2048, ("bits", 30, 2), 30, 17, 2), (16384, ("bits", 30, 3), 16, 2, 1),
+                                                  (32768, ("bits", 30, 2), 16, 2, 2), (4096, ("bits", 40, 2), 20, 3, 3), (2048, ("bits", 60, 2), 32, 2, 2),
+                                                  (256, ("bits", 250, 1), 64, 2, 2)])
+@pytest.mark.parametrize("fused", [True, False])
+def test_blind_rotate_loop_matches_oracle(eng, oracle, monkeypatch, n, spec, w, batch, steps, fused):
+    """fhe_blind_rotate: `steps` external products with a different RGSW row set and different shifts per step; the fused
+    one-launch-per-step path (ping-pong buffers, odd and even step counts) and the general composition both equal the oracle."""
+    if not fused:
+        monkeypatch.setenv("FHE_HIP_NO_FUSED_BLIND_ROTATE", "1")
+    moduli = _moduli(spec, n); L = len(moduli)
+    e = eng.RnsNttEngine(n, moduli); rp = oracle.RnsPlan(n, moduli)
+    K = e.relin_num_digits(w)
+    rows = [[(_random_keys(moduli, n, L * K, 7000 + 100 * c + 1000 * s), _random_keys(moduli, n, L * K, 8000 + 100 * c + 1000 * s)) for c in range(2)]
+            for s in range(steps)]
+    imported = [[e.import_relin_keys(w, [_up(eng, k) for k in kb], [_up(eng, k) for k in ka]) for kb, ka in r] for r in rows]
+    a0, a1 = rns_poly(611, moduli, n, batch), rns_poly(612, moduli, n, batch)
+    rng = np.random.default_rng(5)
+    shifts = rng.integers(0, 2 * n, size=(steps, batch), dtype=np.uint32)
+    shifts[0, :min(batch, 5)] = [0, 1, n - 1, n, 2 * n - 1][:min(batch, 5)]
+    dSh = eng.DeviceBuffer.from_numpy(shifts)
+    dA0, dA1 = _up(eng, a0), _up(eng, a1)
+    dT0, dT1 = eng.DeviceBuffer(a0.nbytes), eng.DeviceBuffer(a0.nbytes)
+    e.blind_rotate([r[0] for r in imported], [r[1] for r in imported], dA0, dA1, dSh, dT0, dT1, batch)
+    w0, w1 = rp.blind_rotate(w, a0, a1, shifts, [r[0] for r in rows], [r[1] for r in rows], threads=8)
+    assert np.array_equal(dA0.download(a0.shape), w0) and np.array_equal(dA1.download(a0.shape), w1)
+    e.check_canonical(dA0, batch); e.check_canonical(dA1, batch)
+
+
+def test_blind_rotate_rejects_bad_arguments(eng):
+    n = 2048; moduli = eng.find_ntt_primes(30, n, 2)
+    e = eng.RnsNttEngine(n, moduli); e2 = eng.RnsNttEngine(n, moduli)
+    K = e.relin_num_digits(16)
+    keys = [_up(eng, k) for k in _random_keys(moduli, n, 2 * K, 1)]
+    r = e.import_relin_keys(16, keys, keys); r_other = e2.import_relin_keys(16, keys, keys)
+    bufs = [eng.DeviceBuffer(2 * n * 32) for _ in range(4)]
+    dSh = eng.DeviceBuffer.from_numpy(np.zeros(1, dtype=np.uint32))
+    with pytest.raises(eng.FheError):
+        e.blind_rotate_step(r, r_other, bufs[0], bufs[1], dSh, bufs[2], bufs[3], 1)      # rows of another engine
+    with pytest.raises(eng.FheError):
+        e.blind_rotate_step(r, r, bufs[0], bufs[1], dSh, bufs[0], bufs[3], 1)            # scratch aliases an accumulator
+    e.blind_rotate([], [], bufs[0], bufs[1], dSh, bufs[2], bufs[3], 1)                   # zero steps: no-op
+
+
 def test_blind_rotation_rotates_the_plaintext_on_gpu(eng, oracle):
     """Three blind-rotation steps with secret bits 1, 0, 1 (toy BGV on the host, N = 2048): the decrypted accumulator is
     X^(sum a_i s_i) * m."""
