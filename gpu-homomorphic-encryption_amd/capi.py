@@ -79,6 +79,14 @@ def lib():
         "fhe_blind_rotate_step": ([vp, vp, vp, vp, vp, vp, vp, vp, u32], ci),
         "fhe_blind_rotate": ([vp, P(vp), P(vp), u32, vp, vp, vp, vp, vp, u32], ci),
         "fhe_rns_fast_base_convert": ([vp, vp, vp, vp, u32], ci),
+        "fhe_sample_uniform_lcg": ([vp, U64x4, u64, sz, vp], ci),
+        "fhe_sample_gaussian_placeholder": ([vp, U64x4, u64, sz, vp], ci),
+        "fhe_rns_sample_ternary": ([vp, vp, ctypes.c_double, u64, u32], ci),
+        "fhe_rns_sample_gaussian": ([vp, vp, ctypes.c_double, u64, u32], ci),
+        "fhe_rns_sample_uniform": ([vp, vp, u64, u32], ci),
+        "fhe_gaussian_cdt": ([ctypes.c_double, P(u64), u32, P(u32)], ci),
+        "fhe_poly_mod_switch": ([vp, vp, U64x4, U64x4, sz, vp], ci),
+        "fhe_negacyclic_reduce": ([vp, U64x4, sz, vp], ci),
         "fhe_rns_rescale_drop_last": ([vp, vp, vp, u32], ci),
         "fhe_relin_num_digits": ([vp, u32, P(u32)], ci),
         "fhe_relin_keys_create": ([vp, P(vp), u32, P(vp), P(vp), u32], ci),
@@ -191,6 +199,28 @@ def _ptr(x):
 
 
 # ---- literal element-wise primitives ----------------------------------------------------------------
+def sample_uniform_lcg(out, q, seed, count, stream=None):
+    _check(lib().fhe_sample_uniform_lcg(_ptr(out), _q4(q), seed, count, stream))
+
+
+def sample_gaussian_placeholder(out, q, seed, count, stream=None):
+    _check(lib().fhe_sample_gaussian_placeholder(_ptr(out), _q4(q), seed, count, stream))
+
+
+def gaussian_cdt(sigma):
+    n = ctypes.c_uint32(0); _check(lib().fhe_gaussian_cdt(sigma, None, 0, ctypes.byref(n)))
+    t = (ctypes.c_uint64 * n.value)(); _check(lib().fhe_gaussian_cdt(sigma, t, n.value, ctypes.byref(n)))
+    return [int(v) for v in t]
+
+
+def poly_mod_switch(r, a, old_q, new_q, count, stream=None):
+    _check(lib().fhe_poly_mod_switch(_ptr(r), _ptr(a), _q4(old_q), _q4(new_q), count, stream))
+
+
+def negacyclic_reduce(data, q, n, stream=None):
+    _check(lib().fhe_negacyclic_reduce(_ptr(data), _q4(q), n, stream))
+
+
 def u256_add_mod(r, a, b, q, count, stream=None):
     _check(lib().fhe_u256_add_mod(_ptr(r), _ptr(a), _ptr(b), _q4(q), count, stream))
 
@@ -306,6 +336,15 @@ class RnsNttEngine:
         arr = ctypes.c_void_p * max(steps, 1)
         a0 = arr(*[r.h for r in rows_c0]); a1 = arr(*[r.h for r in rows_c1])
         _check(lib().fhe_blind_rotate(self.h, a0, a1, steps, _ptr(d_acc0), _ptr(d_acc1), _ptr(d_shifts), _ptr(d_tmp0), _ptr(d_tmp1), batch))
+
+    def sample_ternary(self, d_out, probability, seed, batch=1):
+        _check(lib().fhe_rns_sample_ternary(self.h, _ptr(d_out), probability, seed, batch))
+
+    def sample_gaussian(self, d_out, sigma, seed, batch=1):
+        _check(lib().fhe_rns_sample_gaussian(self.h, _ptr(d_out), sigma, seed, batch))
+
+    def sample_uniform(self, d_out, seed, batch=1):
+        _check(lib().fhe_rns_sample_uniform(self.h, _ptr(d_out), seed, batch))
 
     def fast_base_convert(self, target, d_out, d_in, batch=1):
         _check(lib().fhe_rns_fast_base_convert(self.h, target.h, _ptr(d_out), _ptr(d_in), batch))

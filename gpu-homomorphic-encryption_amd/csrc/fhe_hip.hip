@@ -3,6 +3,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -13,6 +14,7 @@
 
 #include "host_math.hpp"
 #include "ntt256.hip.h"
+#include "sampling.hip.h"
 #include "lds_launch.h"
 #include "ntt_lds.hip.h"
 
@@ -195,6 +197,7 @@ struct fhe_rns_ntt {
     const void *bconv_target = nullptr;
     fhe_dev::CrtBig crt_big;
     int crt_state = 0;                   // 0 = not built, 1 = ready, -1 = Q too large for from_rns (to_rns still fine)
+    double cdt_sigma = 0; uint64_t *d_cdt = nullptr; uint32_t cdt_len = 0;   // cumulative table of the last Gaussian sampler call
 };
 struct fhe_ntt { fhe_rns_ntt *impl; };
 
@@ -202,6 +205,7 @@ static void destroy_impl(fhe_rns_ntt *h) {
     if (!h) return;
     for (void *p : h->d_tables) (void)hipFree(p);
     if (h->d_ws) (void)hipFree(h->d_ws);
+    if (h->d_cdt) (void)hipFree(h->d_cdt);
     if (h->d_flag) (void)hipFree(h->d_flag);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
@@ -954,6 +958,119 @@ extern "C" int fhe_blind_rotate(fhe_rns_ntt_t *h, const fhe_relin_keys_t *const 
 extern "C" int fhe_blind_rotate_step(fhe_rns_ntt_t *h, const fhe_relin_keys_t *rows_c0, const fhe_relin_keys_t *rows_c1, void *d_acc0, void *d_acc1,
                                      const uint32_t *d_shifts, void *d_tmp0, void *d_tmp1, uint32_t batch) {
     return fhe_blind_rotate(h, &rows_c0, &rows_c1, 1, d_acc0, d_acc1, d_shifts, d_tmp0, d_tmp1, batch);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// scheme plumbing around the hot path: samplers, single-modulus modulus switch, negacyclic fold
+// ------------------------------------------------------------------------------------------------------
+template <int KIND>
+static int sample_literal(void *d_out, const uint64_t q[4], uint64_t seed, size_t count, void *stream, const char *what) {
+    if (!d_out || !q) return fail(FHE_ERR_INVALID_ARG, std::string(what) + ": null argument");
+    if (!q[0]) return fail(FHE_ERR_BAD_MODULUS, std::string(what) + ": modulus.limbs[0] is zero (the reference would divide by zero)");
+    if (count > 0xffffffffull) return fail(FHE_ERR_INVALID_ARG, std::string(what) + ": the reference indexes with a uint32_t");
+    int rc = ensure_device(); if (rc) return rc;
+    if (!count) return FHE_OK;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(fhe_dev::sample_literal_kernel<KIND>, dim3(ew_grid(count)), dim3(256), 0, (hipStream_t)stream, (fhe_dev::u256 *)d_out, q[0], seed, count);
+    return post_launch((hipStream_t)stream, what);
+}
+extern "C" int fhe_sample_uniform_lcg(void *d_out, const uint64_t q[4], uint64_t seed, size_t count, void *stream) {
+    return sample_literal<0>(d_out, q, seed, count, stream, "fhe_sample_uniform_lcg");
+}
+extern "C" int fhe_sample_gaussian_placeholder(void *d_out, const uint64_t q[4], uint64_t seed, size_t count, void *stream) {
+    return sample_literal<1>(d_out, q, seed, count, stream, "fhe_sample_gaussian_placeholder");
+}
+
+// Cumulative table of the discrete Gaussian D_sigma over the integers, cut at 12 sigma:  w_k = exp(-k^2 / (2 sigma^2)),
+// Z = w_0 + 2 sum_{k=1..len} w_k, table[k] = floor(2^64 * P(|X| <= k)) for k = 0 .. len-1 (clamped to 2^64 - 1).
+// Plain IEEE double arithmetic in a fixed order, so the CPU oracle's table is identical.
+extern "C" int fhe_gaussian_cdt(double sigma, uint64_t *table, uint32_t capacity, uint32_t *len_out) {
+    if (!len_out) return fail(FHE_ERR_INVALID_ARG, "gaussian_cdt: null argument");
+    if (!(sigma > 0) || sigma > 1e6) return fail(FHE_ERR_INVALID_ARG, "gaussian_cdt: sigma must be in (0, 1e6]");
+    uint32_t len = (uint32_t)std::ceil(sigma * 12.0);
+    if (len < 1) len = 1;
+    *len_out = len;
+    if (!table) return FHE_OK;                                    // size query
+    if (capacity < len) return fail(FHE_ERR_INVALID_ARG, "gaussian_cdt: table too small");
+    const double den = (2.0 * sigma) * sigma;
+    std::vector<double> w(len + 1);
+    for (uint32_t k = 0; k <= len; k++) w[k] = std::exp(-((double)k * (double)k) / den);
+    double Z = w[0];
+    for (uint32_t k = 1; k <= len; k++) Z += 2.0 * w[k];
+    double cum = 0;
+    for (uint32_t k = 0; k < len; k++) {
+        const double term = (k == 0 ? w[0] : 2.0 * w[k]) / Z;
+        cum += term;
+        const double scaled = cum * 18446744073709551616.0;
+        table[k] = scaled >= 18446744073709551615.0 ? ~0ull : (uint64_t)scaled;
+    }
+    return FHE_OK;
+}
+static bool small_fits(const fhe_rns_ntt *h, uint64_t max_magnitude) {   // max_magnitude < every q_l ?
+    for (const U256 &q : h->moduli) if (!(q.w[1] | q.w[2] | q.w[3]) && q.w[0] <= max_magnitude) return false;
+    return true;
+}
+extern "C" int fhe_rns_sample_ternary(fhe_rns_ntt_t *h, void *d_out, double probability, uint64_t seed, uint32_t batch) {
+    int rc = check_call(h, batch, "rns_sample_ternary"); if (rc) return rc;
+    if (!d_out) return fail(FHE_ERR_INVALID_ARG, "rns_sample_ternary: null output");
+    if (!(probability >= 0.0 && probability <= 1.0)) return fail(FHE_ERR_INVALID_ARG, "rns_sample_ternary: probability must be in [0, 1]");
+    if ((rc = ensure_crt(h))) return rc;
+    const uint64_t thr = (uint64_t)(probability * 4294967296.0);
+    const size_t count = (size_t)batch * h->n;
+    hipLaunchKernelGGL(fhe_dev::sample_small_kernel<0>, dim3(ew_grid(count)), dim3(256), 0, h->stream, (fhe_dev::u256 *)d_out,
+                       (const fhe_dev::CrtLimb *)h->d_crt, h->L, h->log_n, seed, thr, (const uint64_t *)nullptr, 0u, count);
+    return post_launch(h->stream, "sample_small_kernel<ternary>");
+}
+extern "C" int fhe_rns_sample_gaussian(fhe_rns_ntt_t *h, void *d_out, double sigma, uint64_t seed, uint32_t batch) {
+    int rc = check_call(h, batch, "rns_sample_gaussian"); if (rc) return rc;
+    if (!d_out) return fail(FHE_ERR_INVALID_ARG, "rns_sample_gaussian: null output");
+    if (h->cdt_sigma != sigma || !h->d_cdt) {
+        uint32_t len = 0;
+        if ((rc = fhe_gaussian_cdt(sigma, nullptr, 0, &len))) return rc;
+        if (!small_fits(h, len)) return fail(FHE_ERR_INVALID_ARG, "rns_sample_gaussian: 12 sigma does not fit below the smallest modulus");
+        std::vector<uint64_t> t(len);
+        if ((rc = fhe_gaussian_cdt(sigma, t.data(), len, &len))) return rc;
+        HIP_TRY(hipStreamSynchronize(h->stream));                 // an earlier launch may still read the old table
+        if (h->d_cdt) { HIP_TRY(hipFree(h->d_cdt)); h->d_cdt = nullptr; }
+        HIP_TRY(hipMalloc((void **)&h->d_cdt, len * sizeof(uint64_t)));
+        HIP_TRY(hipMemcpy(h->d_cdt, t.data(), len * sizeof(uint64_t), hipMemcpyHostToDevice));
+        h->cdt_sigma = sigma; h->cdt_len = len;
+    }
+    if ((rc = ensure_crt(h))) return rc;
+    const size_t count = (size_t)batch * h->n;
+    hipLaunchKernelGGL(fhe_dev::sample_small_kernel<1>, dim3(ew_grid(count)), dim3(256), 0, h->stream, (fhe_dev::u256 *)d_out,
+                       (const fhe_dev::CrtLimb *)h->d_crt, h->L, h->log_n, seed, (uint64_t)0, (const uint64_t *)h->d_cdt, h->cdt_len, count);
+    return post_launch(h->stream, "sample_small_kernel<gaussian>");
+}
+extern "C" int fhe_rns_sample_uniform(fhe_rns_ntt_t *h, void *d_out, uint64_t seed, uint32_t batch) {
+    int rc = check_call(h, batch, "rns_sample_uniform"); if (rc) return rc;
+    if (!d_out) return fail(FHE_ERR_INVALID_ARG, "rns_sample_uniform: null output");
+    if ((rc = ensure_crt(h))) return rc;
+    const size_t count = (size_t)batch * h->L * h->n;
+    hipLaunchKernelGGL(fhe_dev::sample_uniform_rns_kernel, dim3(ew_grid(count)), dim3(256), 0, h->stream, (fhe_dev::u256 *)d_out,
+                       (const fhe_dev::CrtLimb *)h->d_crt, h->L, h->log_n, seed, count);
+    return post_launch(h->stream, "sample_uniform_rns_kernel");
+}
+extern "C" int fhe_poly_mod_switch(void *d_r, const void *d_a, const uint64_t old_q[4], const uint64_t new_q[4], size_t count, void *stream) {
+    if (!d_r || !d_a || !old_q || !new_q) return fail(FHE_ERR_INVALID_ARG, "poly_mod_switch: null argument");
+    U256 O = U256::from(old_q);
+    if (O.bit_length() < 2 || (O.w[3] >> 63)) return fail(FHE_ERR_BAD_MODULUS, "poly_mod_switch: old modulus must be in [2, 2^255)");
+    if (new_q[1] | new_q[2] | new_q[3]) return fail(FHE_ERR_UNSUPPORTED, "poly_mod_switch: the new modulus must be below 2^64");
+    if (!new_q[0]) return fail(FHE_ERR_BAD_MODULUS, "poly_mod_switch: new modulus is zero");
+    int rc = ensure_device(); if (rc) return rc;
+    if (!count) return FHE_OK;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(fhe_dev::poly_mod_switch_kernel, dim3(ew_grid(count)), dim3(256), 0, (hipStream_t)stream, (fhe_dev::u256 *)d_r,
+                       (const fhe_dev::u256 *)d_a, to_dev(old_q), new_q[0], count);
+    return post_launch((hipStream_t)stream, "poly_mod_switch_kernel");
+}
+extern "C" int fhe_negacyclic_reduce(void *d_data, const uint64_t q[4], size_t n, void *stream) {
+    if (!d_data || !q) return fail(FHE_ERR_INVALID_ARG, "negacyclic_reduce: null argument");
+    int rc = ensure_device(); if (rc) return rc;
+    if (!n) return FHE_OK;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(fhe_dev::negacyclic_reduce_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, (fhe_dev::u256 *)d_data, to_dev(q), n);
+    return post_launch((hipStream_t)stream, "negacyclic_reduce_kernel");
 }
 
 // ------------------------------------------------------------------------------------------------------

@@ -197,6 +197,35 @@ int fhe_blind_rotate_step(fhe_rns_ntt_t *h, const fhe_relin_keys_t *rows_c0, con
 int fhe_blind_rotate(fhe_rns_ntt_t *h, const fhe_relin_keys_t *const *rows_c0, const fhe_relin_keys_t *const *rows_c1, uint32_t steps,
                      void *d_acc0, void *d_acc1, const uint32_t *d_shifts, void *d_tmp0, void *d_tmp1, uint32_t batch);
 
+/* ---- scheme plumbing around the hot path ------------------------------------------------ */
+/* sample_uniform_kernel (src/polynomial.cu:130-143), LITERAL: out[i] = ((seed + i) * 1103515245 + 12345) % q.limbs[0] in 64-bit
+ * wrap-around arithmetic ("Simple LCG for demonstration"); called by FHEContext::sample_uniform_polynomial (src/fhe.cu:245-250).
+ * count <= 2^32 (the reference's index is a uint32_t); stream may be NULL. */
+int fhe_sample_uniform_lcg(void *d_out, const uint64_t q[4], uint64_t seed, size_t count, void *stream);
+/* sample_gaussian_kernel (src/polynomial.cu:113-128), LITERAL placeholder: out[i] = (seed + i) % q.limbs[0] (sigma is ignored
+ * there); called by FHEContext::sample_error_polynomial (src/fhe.cu:238-243).  Not a Gaussian: see fhe_rns_sample_gaussian. */
+int fhe_sample_gaussian_placeholder(void *d_out, const uint64_t q[4], uint64_t seed, size_t count, void *stream);
+/* The samplers the reference declares or leaves as placeholders, on the RNS layout [batch][L][n] (a small signed integer is
+ * embedded identically in every limb: -m -> q_l - m).  Counter-based generator over (seed, coefficient index): results do not
+ * depend on the launch shape and equal the CPU oracle's bit for bit.
+ *   ternary : sample_ternary_kernel(result, modulus, probability, seed, n) (include/polynomial.cuh:129-135, declared only; called
+ *             with probability 0.5 by src/fhe.cu:252-257): P(coefficient != 0) = probability, sign uniform.
+ *   gaussian: discrete Gaussian of parameter sigma over the integers, cut at 12 sigma, by inversion of the cumulative table
+ *             fhe_gaussian_cdt builds (what sample_gaussian_kernel's comment asks for, src/polynomial.cu:122-123).
+ *   uniform : residues uniform in [0, q_l) per limb, rejection sampling (no modulo bias), any modulus width. */
+int fhe_rns_sample_ternary(fhe_rns_ntt_t *h, void *d_out, double probability, uint64_t seed, uint32_t batch);
+int fhe_rns_sample_gaussian(fhe_rns_ntt_t *h, void *d_out, double sigma, uint64_t seed, uint32_t batch);
+int fhe_rns_sample_uniform(fhe_rns_ntt_t *h, void *d_out, uint64_t seed, uint32_t batch);
+/* Host helper: table[k] = floor(2^64 * P(|X| <= k)), k = 0 .. len-1, len = ceil(12 sigma); table == NULL queries len. */
+int fhe_gaussian_cdt(double sigma, uint64_t *table, uint32_t capacity, uint32_t *len);
+/* poly_mod_switch_kernel(result, a, old_modulus, new_modulus, n) (include/polynomial.cuh:96-103, declared; launched by
+ * FHEContext::decrypt, src/fhe.cu:181-184: "scale down by delta and reduce mod t"):
+ * r[i] = round(a[i] * new_q / old_q) mod new_q (round half up) on single-modulus containers; a < old_q < 2^255, new_q < 2^64. */
+int fhe_poly_mod_switch(void *d_r, const void *d_a, const uint64_t old_q[4], const uint64_t new_q[4], size_t count, void *stream);
+/* negacyclic_reduce_kernel(data, modulus, n) (include/polynomial.cuh:105-110, declared): fold 2n coefficients modulo x^n + 1,
+ * data[i] = sub_mod(data[i], data[i + n]) for i < n (the upper half is left unchanged). */
+int fhe_negacyclic_reduce(void *d_data, const uint64_t q[4], size_t n, void *stream);
+
 /* Scan a [batch][L][n] buffer for coefficients that are not canonical (>= q_limb, or non-zero
  * upper limbs on the narrow paths).  Synchronises.  FHE_OK or FHE_ERR_NONCANONICAL. */
 int fhe_rns_check_canonical(fhe_rns_ntt_t *h, const void *d_data, uint32_t batch);

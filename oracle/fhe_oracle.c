@@ -7,6 +7,7 @@
  */
 #include "fhe_oracle.h"
 
+#include <math.h>
 #include <stdlib.h>
 #include <string.h>
 #ifdef _OPENMP
@@ -629,4 +630,116 @@ void orc_monomial_mul_sub(orc_plan *const *plans, uint32_t L, orc_u256 *out, con
             }
         }
     }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* Row N4: samplers, single-modulus modulus switch, negacyclic fold                             */
+/* ------------------------------------------------------------------------------------------ */
+/* sample_uniform_kernel (src/polynomial.cu:130-143), literal: ((seed + idx) * 1103515245 + 12345) % modulus.limbs[0],
+ * uint64 wrap-around, idx a uint32_t. */
+void orc_sample_uniform_lcg(orc_u256 *out, const orc_u256 *q, uint64_t seed, size_t count) {
+    for (size_t i = 0; i < count; i++) {
+        uint32_t idx = (uint32_t)i;
+        out[i] = u256_from(((seed + idx) * 1103515245ull + 12345ull) % q->limbs[0]);
+    }
+}
+/* sample_gaussian_kernel (src/polynomial.cu:113-128), literal placeholder: (seed + idx) % modulus.limbs[0]. */
+void orc_sample_gaussian_placeholder(orc_u256 *out, const orc_u256 *q, uint64_t seed, size_t count) {
+    for (size_t i = 0; i < count; i++) out[i] = u256_from((seed + (uint32_t)i) % q->limbs[0]);
+}
+
+/* Counter-based generator shared (by specification, not by code) with the device samplers: SplitMix64's output function over
+ * (seed, element index, draw number). */
+static uint64_t sm64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+static uint64_t ctr_rand(uint64_t seed, uint64_t index, uint64_t draw) { return sm64(sm64(seed ^ (index * 0xD1342543DE82EF95ull)) + draw); }
+uint64_t orc_ctr_rand(uint64_t seed, uint64_t index, uint64_t draw) { return ctr_rand(seed, index, draw); }
+
+static void embed_small(orc_plan *const *plans, uint32_t L, orc_u256 *out, size_t b, size_t x, uint64_t mag, int neg) {
+    const uint32_t n = plans[0]->n;
+    for (uint32_t l = 0; l < L; l++) {
+        orc_u256 v = u256_from(mag);
+        if (neg && mag) { orc_u256 t; sub256(t.limbs, plans[l]->q.limbs, v.limbs); v = t; }
+        out[(b * L + l) * n + x] = v;
+    }
+}
+/* sample_ternary_kernel (include/polynomial.cuh:129-135, declared only): nonzero with probability thr / 2^32, sign uniform. */
+void orc_sample_ternary(orc_plan *const *plans, uint32_t L, orc_u256 *out, uint64_t thr, uint64_t seed, uint32_t batch) {
+    const uint32_t n = plans[0]->n;
+    for (size_t g = 0; g < (size_t)batch * n; g++) {
+        uint64_t r = ctr_rand(seed, g, 0);
+        embed_small(plans, L, out, g / n, g % n, (r & 0xffffffffull) < thr ? 1 : 0, (int)(r >> 63));
+    }
+}
+/* Cumulative table of the discrete Gaussian cut at 12 sigma: table[k] = floor(2^64 P(|X| <= k)); returns len = ceil(12 sigma). */
+uint32_t orc_gaussian_cdt(double sigma, uint64_t *table, uint32_t capacity) {
+    uint32_t len = (uint32_t)ceil(sigma * 12.0);
+    if (len < 1) len = 1;
+    if (!table || capacity < len) return len;
+    const double den = (2.0 * sigma) * sigma;
+    double *w = (double *)malloc((len + 1) * sizeof(double));
+    for (uint32_t k = 0; k <= len; k++) w[k] = exp(-((double)k * (double)k) / den);
+    double Z = w[0];
+    for (uint32_t k = 1; k <= len; k++) Z += 2.0 * w[k];
+    double cum = 0;
+    for (uint32_t k = 0; k < len; k++) {
+        const double term = (k == 0 ? w[0] : 2.0 * w[k]) / Z;
+        cum += term;
+        const double scaled = cum * 18446744073709551616.0;
+        table[k] = scaled >= 18446744073709551615.0 ? ~0ull : (uint64_t)scaled;
+    }
+    free(w);
+    return len;
+}
+void orc_sample_gaussian(orc_plan *const *plans, uint32_t L, orc_u256 *out, const uint64_t *cdt, uint32_t len, uint64_t seed, uint32_t batch) {
+    const uint32_t n = plans[0]->n;
+    for (size_t g = 0; g < (size_t)batch * n; g++) {
+        uint64_t r = ctr_rand(seed, g, 1), m = 0;
+        for (uint32_t j = 0; j < len; j++) m += r >= cdt[j];
+        embed_small(plans, L, out, g / n, g % n, m, (int)(ctr_rand(seed, g, 2) >> 63));
+    }
+}
+/* Uniform residues in [0, q_l): rejection on draws masked to the bit length of q_l; draw t uses words 16 + 4t .. 16 + 4t + 3. */
+void orc_sample_uniform(orc_plan *const *plans, uint32_t L, orc_u256 *out, uint64_t seed, uint32_t batch) {
+    const uint32_t n = plans[0]->n;
+    for (size_t g = 0; g < (size_t)batch * L * n; g++) {
+        const orc_u256 *q = &plans[(g / n) % L]->q;
+        int top = 3; while (top > 0 && q->limbs[top] == 0) top--;
+        int bits = 64 - __builtin_clzll(q->limbs[top]);
+        uint64_t mask = bits == 64 ? ~0ull : ((1ull << bits) - 1);
+        orc_u256 v;
+        for (uint32_t t = 0;; t++) {
+            for (int i = 0; i < 4; i++) v.limbs[i] = i <= top ? ctr_rand(seed, g, 16 + 4 * (uint64_t)t + i) : 0;
+            v.limbs[top] &= mask;
+            if (u256_gt(q, &v)) break;
+            if (t == 63) { v.limbs[top] &= mask >> 1; break; }
+        }
+        out[g] = v;
+    }
+}
+/* poly_mod_switch_kernel (include/polynomial.cuh:96-103, declared; FHEContext::decrypt src/fhe.cu:181-184):
+ * round(a * new_q / old_q) mod new_q, half up, a < old_q < 2^255, new_q < 2^64.  Restoring division of the 320-bit numerator. */
+void orc_poly_mod_switch(orc_u256 *out, const orc_u256 *in, const orc_u256 *old_q, uint64_t new_q, size_t count) {
+    orc_u256 half = *old_q; u256_shr(&half, 1);
+    for (size_t g = 0; g < count; g++) {
+        uint64_t p[5]; unsigned __int128 c = 0;
+        for (int i = 0; i < 4; i++) { c += (unsigned __int128)in[g].limbs[i] * new_q + half.limbs[i]; p[i] = (uint64_t)c; c >>= 64; }
+        p[4] = (uint64_t)c;
+        orc_u256 rem = u256_from(0); unsigned __int128 quo = 0;
+        for (int bit = 319; bit >= 0; bit--) {
+            for (int i = 3; i > 0; i--) rem.limbs[i] = (rem.limbs[i] << 1) | (rem.limbs[i - 1] >> 63);
+            rem.limbs[0] = (rem.limbs[0] << 1) | ((p[bit >> 6] >> (bit & 63)) & 1);
+            quo <<= 1;
+            if (!u256_gt(old_q, &rem)) { orc_u256 t; sub256(t.limbs, rem.limbs, old_q->limbs); rem = t; quo |= 1; }
+        }
+        out[g] = u256_from((uint64_t)(quo % new_q));
+    }
+}
+/* negacyclic_reduce_kernel (include/polynomial.cuh:105-110, declared): data[i] = sub_mod(data[i], data[i + n]), i < n. */
+void orc_negacyclic_reduce(orc_u256 *data, const orc_u256 *q, size_t n) {
+    for (size_t i = 0; i < n; i++) { orc_u256 t; orc_sub_mod(&t, &data[i], &data[i + n], q); data[i] = t; }
 }

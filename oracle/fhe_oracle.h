@@ -135,6 +135,20 @@ void orc_fast_base_convert(orc_plan *const *src, uint32_t L, orc_plan *const *ds
  * pair (orc_relinearize with c2 := d0 and the rows for component 0, then c2 := d1 with the rows for component 1).
  * This function is the remaining piece: out[b][l][x] = ((X^shift[b] - 1) * in[b][l])[x] over Z_q[x]/(x^n + 1), shift in [0, 2n). */
 void orc_monomial_mul_sub(orc_plan *const *plans, uint32_t L, orc_u256 *out, const orc_u256 *in, const uint32_t *shifts, uint32_t batch);
+/* ---- row N4: samplers, single-modulus modulus switch, negacyclic fold ---------------------------------- */
+/* Literal restatements of the two sampler kernels the reference defines (src/polynomial.cu:113-143). */
+void orc_sample_uniform_lcg(orc_u256 *out, const orc_u256 *q, uint64_t seed, size_t count);
+void orc_sample_gaussian_placeholder(orc_u256 *out, const orc_u256 *q, uint64_t seed, size_t count);
+/* The declared-only / placeholder samplers as built here (parity unpinned against the reference; pinned by distribution
+ * tests): counter-based SplitMix64 draws per coefficient, small values embedded in every limb of [batch][L][n]. */
+uint64_t orc_ctr_rand(uint64_t seed, uint64_t index, uint64_t draw);
+void orc_sample_ternary(orc_plan *const *plans, uint32_t L, orc_u256 *out, uint64_t thr, uint64_t seed, uint32_t batch);
+uint32_t orc_gaussian_cdt(double sigma, uint64_t *table, uint32_t capacity);
+void orc_sample_gaussian(orc_plan *const *plans, uint32_t L, orc_u256 *out, const uint64_t *cdt, uint32_t len, uint64_t seed, uint32_t batch);
+void orc_sample_uniform(orc_plan *const *plans, uint32_t L, orc_u256 *out, uint64_t seed, uint32_t batch);
+/* poly_mod_switch_kernel / negacyclic_reduce_kernel (include/polynomial.cuh:96-110, declared only). */
+void orc_poly_mod_switch(orc_u256 *out, const orc_u256 *in, const orc_u256 *old_q, uint64_t new_q, size_t count);
+void orc_negacyclic_reduce(orc_u256 *data, const orc_u256 *q, size_t n);
 int orc_max_threads(void);
 
 #ifdef __cplusplus

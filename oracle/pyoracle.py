@@ -72,6 +72,15 @@ def lib():
             "orc_rns_polymul": (ci, [ctypes.POINTER(vp), u32, P, P, P, u32, ci]),
             "orc_ct_multiply": (ci, [ctypes.POINTER(vp), u32] + [P] * 7 + [u32, ci]),
             "orc_max_threads": (ci, []),
+            "orc_sample_uniform_lcg": (None, [P, P, u64, sz]),
+            "orc_sample_gaussian_placeholder": (None, [P, P, u64, sz]),
+            "orc_ctr_rand": (u64, [u64, u64, u64]),
+            "orc_sample_ternary": (None, [ctypes.POINTER(vp), u32, P, u64, u64, u32]),
+            "orc_gaussian_cdt": (u32, [ctypes.c_double, ctypes.POINTER(u64), u32]),
+            "orc_sample_gaussian": (None, [ctypes.POINTER(vp), u32, P, ctypes.POINTER(u64), u32, u64, u32]),
+            "orc_sample_uniform": (None, [ctypes.POINTER(vp), u32, P, u64, u32]),
+            "orc_poly_mod_switch": (None, [P, P, P, u64, sz]),
+            "orc_negacyclic_reduce": (None, [P, P, sz]),
             "orc_to_rns": (None, [ctypes.POINTER(vp), u32, P, P, u32]),
             "orc_from_rns": (ci, [ctypes.POINTER(vp), u32, P, P, u32]),
             "orc_monomial_mul_sub": (None, [ctypes.POINTER(vp), u32, P, P, ctypes.POINTER(u32), u32]),
@@ -354,6 +363,56 @@ RnsPlan.to_rns = _rns_to_rns
 RnsPlan.from_rns = _rns_from_rns
 RnsPlan.relinearize = _rns_relin
 RnsPlan.num_digits = _rns_num_digits
+
+
+# ---- row N4: samplers, single-modulus modulus switch, negacyclic fold ------------------------------------------
+def sample_uniform_lcg(q, seed, count):
+    """sample_uniform_kernel, literal (src/polynomial.cu:130-143)."""
+    out = np.empty((count, 4), dtype=np.uint64); lib().orc_sample_uniform_lcg(_p(out), _p(_one(q)), seed, count); return out
+
+
+def sample_gaussian_placeholder(q, seed, count):
+    """sample_gaussian_kernel, literal placeholder (src/polynomial.cu:113-128)."""
+    out = np.empty((count, 4), dtype=np.uint64); lib().orc_sample_gaussian_placeholder(_p(out), _p(_one(q)), seed, count); return out
+
+
+def ctr_rand(seed, index, draw):
+    return int(lib().orc_ctr_rand(seed, index, draw))
+
+
+def gaussian_cdt(sigma):
+    n = lib().orc_gaussian_cdt(sigma, None, 0)
+    t = (ctypes.c_uint64 * n)(); lib().orc_gaussian_cdt(sigma, t, n)
+    return [int(v) for v in t]
+
+
+def poly_mod_switch(a, old_q, new_q):
+    _chk(a); out = np.empty_like(a); lib().orc_poly_mod_switch(_p(out), _p(a), _p(_one(old_q)), new_q, a.size // 4); return out
+
+
+def negacyclic_reduce(data, q):
+    _chk(data); d = data.copy(); lib().orc_negacyclic_reduce(_p(d), _p(_one(q)), d.size // 8); return d
+
+
+def _rns_sample_ternary(self, probability, seed, batch=1):
+    out = np.empty((batch, self.L, self.n, 4), dtype=np.uint64)
+    lib().orc_sample_ternary(self._arr, self.L, _p(out), int(probability * 4294967296.0), seed, batch); return out
+
+
+def _rns_sample_gaussian(self, sigma, seed, batch=1):
+    t = gaussian_cdt(sigma); arr = (ctypes.c_uint64 * len(t))(*t)
+    out = np.empty((batch, self.L, self.n, 4), dtype=np.uint64)
+    lib().orc_sample_gaussian(self._arr, self.L, _p(out), arr, len(t), seed, batch); return out
+
+
+def _rns_sample_uniform(self, seed, batch=1):
+    out = np.empty((batch, self.L, self.n, 4), dtype=np.uint64)
+    lib().orc_sample_uniform(self._arr, self.L, _p(out), seed, batch); return out
+
+
+RnsPlan.sample_ternary = _rns_sample_ternary
+RnsPlan.sample_gaussian = _rns_sample_gaussian
+RnsPlan.sample_uniform = _rns_sample_uniform
 
 
 def max_threads():

@@ -774,3 +774,79 @@ def test_blind_rotation_rotates_the_plaintext_on_gpu(eng, oracle):
             j -= n; sign = -sign
         want[j] = (sign * mi) % t
     assert got == want
+
+
+# ------------------------------------------------------------------------------------ N4: samplers, modulus switch, fold
+@pytest.mark.parametrize("q,seed,count", [(12289, 1804289383, 4096), (1 << 60, 846930886, 1000), ((1 << 64) - 59, (1 << 64) - 5, 333),
+                                          ((1 << 200) + 12289, 99, 70000)])
+def test_literal_samplers_match_oracle(eng, oracle, q, seed, count):
+    """sample_uniform_kernel / sample_gaussian_kernel (src/polynomial.cu:113-143), literal, incl. the reference's own modulus 2^60
+    (src/fhe.cu:13) and a multi-limb modulus (only limbs[0] is used)."""
+    d = eng.DeviceBuffer(count * 32)
+    eng.sample_uniform_lcg(d, q, seed, count)
+    assert np.array_equal(d.download((count, 4)), oracle.sample_uniform_lcg(q, seed, count))
+    eng.sample_gaussian_placeholder(d, q, seed, count)
+    assert np.array_equal(d.download((count, 4)), oracle.sample_gaussian_placeholder(q, seed, count))
+    with pytest.raises(eng.FheError):
+        eng.sample_uniform_lcg(d, 1 << 64, seed, count)          # limbs[0] == 0: the reference would divide by zero
+
+
+@pytest.mark.parametrize("n,spec,batch", [(8192, ("bits", 30, 4), 5), (4096, ("bits", 40, 3), 2), (2048, ("bits", 60, 2), 3), (256, ("bits", 250, 2), 2),
+                                          (1024, [12289], 3)])
+def test_rns_samplers_match_oracle(eng, oracle, n, spec, batch):
+    moduli = _moduli(spec, n); L = len(moduli)
+    e = eng.RnsNttEngine(n, moduli); rp = oracle.RnsPlan(n, moduli)
+    d = eng.DeviceBuffer(batch * L * n * 32); shape = (batch, L, n, 4)
+    for p in (0.5, 0.0, 1.0, 0.3):
+        e.sample_ternary(d, p, 1234, batch)
+        assert np.array_equal(d.download(shape), rp.sample_ternary(p, 1234, batch))
+    e.check_canonical(d, batch)
+    for sigma in (3.2, 0.8, 3.2, 19.0):                          # repeated sigma re-uses the cached table
+        assert eng.gaussian_cdt(sigma) == oracle.gaussian_cdt(sigma)
+        e.sample_gaussian(d, sigma, 99, batch)
+        assert np.array_equal(d.download(shape), rp.sample_gaussian(sigma, 99, batch))
+    e.check_canonical(d, batch)
+    e.sample_uniform(d, 2024, batch)
+    assert np.array_equal(d.download(shape), rp.sample_uniform(2024, batch))
+    e.check_canonical(d, batch)
+    with pytest.raises(eng.FheError):
+        e.sample_ternary(d, 1.5, 1, batch)
+    if min(moduli) < 2 ** 20:
+        with pytest.raises(eng.FheError):
+            e.sample_gaussian(d, 2000.0, 1, batch)                # 12 sigma does not fit below q
+
+
+@pytest.mark.parametrize("old_q,new_q", [("p60", 65537), ((1 << 120) + 451, 257), ((1 << 254) + 79, (1 << 64) - 59), (1000003, 2), (12289, 12289)])
+def test_poly_mod_switch_matches_oracle_and_big_integers(eng, oracle, old_q, new_q):
+    if old_q == "p60":
+        old_q = nm.ntt_primes(60, 4096, 1)[0]
+    rng = random.Random(5)
+    a = [0, 1, old_q - 1, old_q // 2, old_q // 2 + 1] + [rng.randrange(old_q) for _ in range(4091)]
+    arr = oracle.to_limbs(a)
+    dA = _up(eng, arr); dR = eng.DeviceBuffer(arr.nbytes)
+    eng.poly_mod_switch(dR, dA, old_q, new_q, len(a))
+    got = dR.download(arr.shape)
+    assert np.array_equal(got, oracle.poly_mod_switch(arr, old_q, new_q))
+    assert oracle.from_limbs(got)[:64] == [((x * new_q + old_q // 2) // old_q) % new_q for x in a[:64]]
+    with pytest.raises(eng.FheError):
+        eng.poly_mod_switch(dR, dA, old_q, 1 << 64, len(a))
+
+
+def test_decrypt_scaling_through_poly_mod_switch(eng, oracle):
+    """FHEContext::decrypt's last step (src/fhe.cu:181-184): m = round(t * x / q) mod t recovers m from x = delta * m + e."""
+    q = nm.ntt_primes(60, 4096, 1)[0]; t = 65537; delta = q // t
+    rng = random.Random(8)
+    m = [rng.randrange(t) for _ in range(4096)]
+    x = [(delta * mi + rng.randrange(-1000, 1000)) % q for mi in m]
+    arr = oracle.to_limbs(x); dA = _up(eng, arr); dR = eng.DeviceBuffer(arr.nbytes)
+    eng.poly_mod_switch(dR, dA, q, t, len(x))
+    assert oracle.from_limbs(dR.download(arr.shape)) == m
+
+
+def test_negacyclic_reduce_matches_oracle(eng, oracle):
+    rng = random.Random(4)
+    for n, q in [(1024, 12289), (4096, nm.ntt_primes(60, 4096, 1)[0]), (300, (1 << 254) + 79)]:
+        d = oracle.to_limbs([rng.randrange(q) for _ in range(2 * n)])
+        dD = _up(eng, d)
+        eng.negacyclic_reduce(dD, q, n)
+        assert np.array_equal(dD.download(d.shape), oracle.negacyclic_reduce(d, q))

@@ -382,3 +382,108 @@ def test_blind_rotate_steps_rotate_the_plaintext(oracle):
         mono = [0] * n; mono[total % n] = 1 if (total // n) % 2 == 0 else t - 1
         want = nm.negacyclic_mul_direct(mono, m, t)
         assert S.decrypt([bgv_toy.from_limb_array(A0), bgv_toy.from_limb_array(A1)]) == want
+
+
+# ---------------------------------------------------------------------------------- N4: samplers, modulus switch, fold
+def test_literal_samplers_match_the_reference_formulas(oracle):
+    """sample_uniform_kernel / sample_gaussian_kernel (src/polynomial.cu:113-143) are deterministic placeholders: restated
+    literally, checked against the formulas in Python integers (64-bit wrap-around)."""
+    M = (1 << 64) - 1
+    for q, seed, count in [(12289, 1804289383, 1024), ((1 << 60), 846930886, 33), ((1 << 64) - 59, (1 << 64) - 5, 100), (2, 0, 7)]:
+        u = oracle.from_limbs(oracle.sample_uniform_lcg(q, seed, count))
+        g = oracle.from_limbs(oracle.sample_gaussian_placeholder(q, seed, count))
+        q0 = q & M
+        assert u == [((((seed + i) & M) * 1103515245 + 12345) & M) % q0 for i in range(count)]
+        assert g == [((seed + i) & M) % q0 for i in range(count)]
+
+
+def _sm64(z):
+    M = (1 << 64) - 1
+    z = (z + 0x9E3779B97F4A7C15) & M
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M
+    return z ^ (z >> 31)
+
+
+def _ctr(seed, index, draw):
+    M = (1 << 64) - 1
+    return _sm64((_sm64(seed ^ ((index * 0xD1342543DE82EF95) & M)) + draw) & M)
+
+
+def test_counter_generator_matches_its_specification(oracle):
+    for seed, idx, draw in [(0, 0, 0), (1, 2, 3), ((1 << 64) - 1, 123456789, 16), (42, 1 << 40, 2)]:
+        assert oracle.ctr_rand(seed, idx, draw) == _ctr(seed, idx, draw)
+    assert _sm64(0) == 0xE220A8397B1DCDAF          # SplitMix64's first output for seed 0 (published test vector)
+
+
+def test_ternary_and_gaussian_samplers(oracle):
+    n = 4096; moduli = nm.ntt_primes(30, n, 2) + nm.ntt_primes(40, n, 1); rp = oracle.RnsPlan(n, moduli)
+    t = rp.sample_ternary(0.5, seed=7, batch=4)
+    vals = []
+    for g in range(4 * n):
+        b, x = divmod(g, n)
+        r = _ctr(7, g, 0); mag = 1 if (r & 0xffffffff) < (1 << 31) else 0; neg = r >> 63
+        for l, q in enumerate(moduli):
+            want = 0 if not mag else (q - 1 if neg else 1)
+            assert int(t[b, l, x, 0]) == want and not t[b, l, x, 1:].any()
+        vals.append(-mag if neg else mag)
+    nz = sum(1 for v in vals if v)
+    assert abs(nz / len(vals) - 0.5) < 0.03 and abs(sum(vals)) < 4 * (len(vals) ** 0.5)
+    assert not rp.sample_ternary(0.0, 1, 1)[..., 0].any()
+    # discrete Gaussian: the table is a CDF, samples have the right variance, limbs agree
+    sigma = 3.2
+    cdt = oracle.gaussian_cdt(sigma)
+    assert len(cdt) == 39 and all(a <= b for a, b in zip(cdt, cdt[1:])) and cdt[-1] >= (1 << 64) - (1 << 20)
+    import math
+    Z = 1 + 2 * sum(math.exp(-k * k / (2 * sigma * sigma)) for k in range(1, 40))
+    assert abs(cdt[0] / 2.0 ** 64 - 1 / Z) < 1e-12
+    g = rp.sample_gaussian(sigma, seed=11, batch=8)
+    c = g[:, 0, :, 0].astype(np.int64).reshape(-1); q0 = moduli[0]
+    c = np.where(c > q0 // 2, c - q0, c)
+    assert abs(c.mean()) < 0.1 and abs(c.var() - sigma * sigma) < 0.5 and np.abs(c).max() <= len(cdt)
+    for l, q in enumerate(moduli):
+        cl = g[:, l, :, 0].astype(np.int64).reshape(-1); cl = np.where(cl > q // 2, cl - q, cl)
+        assert np.array_equal(cl, c)
+
+
+def test_uniform_sampler_is_canonical_and_unbiased(oracle):
+    n = 2048; moduli = nm.ntt_primes(30, n, 1) + nm.ntt_primes(60, n, 1) + nm.ntt_primes(250, n, 1)
+    rp = oracle.RnsPlan(n, moduli)
+    u = rp.sample_uniform(seed=5, batch=3)
+    for l, q in enumerate(moduli):
+        v = oracle.from_limbs(u[:, l])
+        assert all(0 <= x < q for x in v)
+        assert abs(sum(v) / len(v) / q - 0.5) < 0.02
+    # first element by hand: masked draws until one is below q
+    q = moduli[0]; bits = q.bit_length(); t = 0
+    while True:
+        r = _ctr(5, 0, 16 + 4 * t) & ((1 << bits) - 1)
+        if r < q:
+            break
+        t += 1
+    assert int(u[0, 0, 0, 0]) == r
+    assert not np.array_equal(u, rp.sample_uniform(seed=6, batch=3))
+
+
+def test_poly_mod_switch_rounds_like_big_integers(oracle):
+    rng = random.Random(77)
+    cases = [(nm.ntt_primes(60, 4096, 1)[0], 65537), ((1 << 120) + 451, 257), ((1 << 254) + 79, (1 << 64) - 59), (1000003, 2), (12289, 12289)]
+    for old_q, new_q in cases:
+        a = [0, 1, old_q - 1, old_q // 2, old_q // 2 + 1, old_q // new_q, (old_q // (2 * new_q)), (old_q // (2 * new_q)) + 1] + [rng.randrange(old_q) for _ in range(56)]
+        got = oracle.from_limbs(oracle.poly_mod_switch(oracle.to_limbs(a), old_q, new_q))
+        assert got == [((x * new_q + old_q // 2) // old_q) % new_q for x in a]
+
+
+def test_negacyclic_reduce_folds_the_upper_half(oracle):
+    rng = random.Random(3)
+    n, q = 64, 12289
+    d = [rng.randrange(q) for _ in range(2 * n)]
+    out = oracle.from_limbs(oracle.negacyclic_reduce(oracle.to_limbs(d), q))
+    assert out[:n] == [(d[i] - d[i + n]) % q for i in range(n)] and out[n:] == d[n:]
+    # consistent with the negacyclic product: fold(schoolbook over Z[x]) == polymul mod x^n + 1
+    a = [rng.randrange(q) for _ in range(n)]; b = [rng.randrange(q) for _ in range(n)]
+    full = [0] * (2 * n)
+    for i, x in enumerate(a):
+        for j, y in enumerate(b):
+            full[i + j] = (full[i + j] + x * y) % q
+    assert oracle.from_limbs(oracle.negacyclic_reduce(oracle.to_limbs(full), q))[:n] == nm.negacyclic_mul_direct(a, b, q)
