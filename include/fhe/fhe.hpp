@@ -181,14 +181,26 @@ public:
     // undefined kernels; here noise is a multiple of t and plaintexts sit in the low bits: c0 + c1*s = m + t*e).
     // Sampling is done on the host with a seeded std::mt19937_64 (the reference's device samplers are toys, out of scope).
     void seed(uint64_t s) { rng_.seed(s); }
+    // true: keygen / encrypt draw their polynomials with the DEVICE samplers below (seeds taken from the context's generator)
+    void device_sampling(bool on) { device_sampling_ = on; }
+
+    // FHEContext::sample_error_polynomial / sample_uniform_polynomial / sample_ternary_polynomial (src/fhe.cu:237-257) on the
+    // device: discrete Gaussian of parameter security.sigma, uniform residues, ternary with P(nonzero) = 0.5 -- the
+    // distributions the reference names (its kernels are placeholders or undefined; the literal placeholders are
+    // fhe_sample_uniform_lcg / fhe_sample_gaussian_placeholder).  Seeds come from the context generator where the reference calls rand().
+    void sample_error_polynomial(Polynomial &p) {
+        check(fhe_rns_sample_gaussian(params_.rns_ntt->handle(), p.coeffs, (double)params_.security.sigma, rng_(), 1), "sample_error_polynomial");
+    }
+    void sample_uniform_polynomial(Polynomial &p) { check(fhe_rns_sample_uniform(params_.rns_ntt->handle(), p.coeffs, rng_(), 1), "sample_uniform_polynomial"); }
+    void sample_ternary_polynomial(Polynomial &p) { check(fhe_rns_sample_ternary(params_.rns_ntt->handle(), p.coeffs, 0.5, rng_(), 1), "sample_ternary_polynomial"); }
 
     void keygen(PublicKey &pk, SecretKey &sk) {                                            // src/fhe.cu:54-74
         sk.sk = new_polynomial(); pk.pk0 = new_polynomial(); pk.pk1 = new_polynomial();
-        upload_signed(*sk.sk, sample_small(1));                                             // ternary secret (:57)
-        upload_uniform(*pk.pk1);                                                            // :64
+        draw_ternary(*sk.sk);                                                               // ternary secret (:57)
+        draw_uniform(*pk.pk1);                                                              // :64
         std::unique_ptr<Polynomial> as(new_polynomial());
         params_.rns_ntt->multiply_rns(as->coeffs, pk.pk1->coeffs, sk.sk->coeffs);           // :71
-        upload_signed(*pk.pk0, sample_small(3), params_.t);                                 // t*e (:67-68)
+        draw_scaled_error(*pk.pk0);                                                         // t*e (:67-68)
         params_.rns_ntt->sub_rns(pk.pk0->coeffs, pk.pk0->coeffs, as->coeffs);               // pk0 = t*e - pk1*sk (:72)
         device_synchronize();
     }
@@ -223,14 +235,14 @@ public:
         ensure_components(ct, 2);
         RNS_NTTEngine &E = *params_.rns_ntt;
         std::unique_ptr<Polynomial> u(new_polynomial()), e(new_polynomial());
-        upload_signed(*u, sample_small(1));
+        draw_ternary(*u);
         E.multiply_rns(ct.components[0]->coeffs, pk.pk0->coeffs, u->coeffs);                 // pk0*u (:160)
         E.multiply_rns(ct.components[1]->coeffs, pk.pk1->coeffs, u->coeffs);                 // pk1*u (:165)
-        upload_signed(*e, sample_small(3), params_.t);
+        draw_scaled_error(*e);
         E.add_rns(ct.components[0]->coeffs, ct.components[0]->coeffs, e->coeffs);            // + t*e1
         E.add_rns(ct.components[0]->coeffs, ct.components[0]->coeffs, pt.poly->coeffs);      // + m  (:161-162)
         device_synchronize();
-        upload_signed(*e, sample_small(3), params_.t);
+        draw_scaled_error(*e);
         E.add_rns(ct.components[1]->coeffs, ct.components[1]->coeffs, e->coeffs);            // + t*e2 (:166)
         device_synchronize();
         ct.level = 0; ct.noise_budget = 0; ct.is_ntt_form = false;
@@ -272,6 +284,26 @@ public:
 private:
     SchemeParams params_;
     std::mt19937_64 rng_{0x5EED0000ull};
+    bool device_sampling_ = false;
+
+    // ---- where keygen / encrypt get their random polynomials: host generator (default) or the device samplers --------------
+    void draw_ternary(Polynomial &p) { if (device_sampling_) sample_ternary_polynomial(p); else upload_signed(p, sample_small(1)); }
+    void draw_uniform(Polynomial &p) { if (device_sampling_) sample_uniform_polynomial(p); else upload_uniform(p); }
+    // t * e, e small: BGV-style noise (a multiple of the plaintext modulus)
+    void draw_scaled_error(Polynomial &p) {
+        if (!device_sampling_) { upload_signed(p, sample_small(3), params_.t); return; }
+        sample_error_polynomial(p);
+        const uint32_t n = params_.n, L = (uint32_t)params_.rns_moduli.size();
+        for (uint32_t l = 0; l < L; l++) {   // limb l *= t: literal Montgomery product with the scalar t * 2^256 mod q_l (poly_mul_scalar_kernel)
+            const uint256_t &q = params_.rns_moduli[l];
+            if (q.limbs[1] | q.limbs[2] | q.limbs[3]) throw std::runtime_error("FHEContext: device sampling expects word-sized RNS primes");
+            const uint64_t q0 = q.limbs[0], tr = (uint64_t)((unsigned __int128)(params_.t % q0) * pow_mod(2, 256, q0) % q0);
+            uint64_t inv[4]; check(fhe_montgomery_inverse(q.limbs, inv), "montgomery inverse");
+            const uint256_t scalar(tr);
+            check(fhe_u256_mont_mul_scalar(p.coeffs + (size_t)l * n, p.coeffs + (size_t)l * n, scalar.limbs, q.limbs, inv[0], n, nullptr),   // legacy default stream: ordered with the engine's blocking stream
+                  "FHEContext: scale error by t");
+        }
+    }
 
     // ---- host-side helpers of the plumbing above --------------------------------------------------------------------------
     std::vector<long long> sample_small(int bound) {

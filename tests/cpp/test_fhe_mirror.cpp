@@ -275,6 +275,59 @@ static void test_fhe_operations() {
     delete pk.pk0; delete pk.pk1; delete sk.sk; delete pa.poly; delete pb.poly; delete pr.poly;
 }
 
+// The same scenario with every random polynomial drawn by the DEVICE samplers (row N4): ternary secret and encryption
+// randomness, discrete-Gaussian noise of parameter sigma = 3.2 scaled by t, uniform public-key mask (relinkey_gen keeps its host generator).
+static void test_fhe_operations_device_sampling() {
+    std::cout << "Testing FHE Operations with device samplers..." << std::endl;
+    SecurityParams sp{128, 4096, 120, 3.2f, 64};
+    FHEContext ctx(sp);
+    ctx.seed(77); ctx.device_sampling(true);
+    // the samplers themselves: ternary values are 0, 1 or q - 1 in every limb, about half of them non-zero
+    std::unique_ptr<Polynomial> s(ctx.new_polynomial());
+    ctx.sample_ternary_polynomial(*s); device_synchronize();
+    const uint32_t N = 4096; const size_t L = ctx.params().rns_moduli.size();
+    std::vector<uint256_t> h(L * N); copy_to_host(h.data(), s->coeffs, h.size());
+    size_t nz = 0;
+    for (uint32_t i = 0; i < N; i++) {
+        const uint64_t v0 = h[i].limbs[0], q0 = ctx.params().rns_moduli[0].limbs[0];
+        REQUIRE(v0 == 0 || v0 == 1 || v0 == q0 - 1);
+        for (size_t l = 1; l < L; l++) {
+            const uint64_t ql = ctx.params().rns_moduli[l].limbs[0], vl = h[l * N + i].limbs[0];
+            REQUIRE((v0 == 0 && vl == 0) || (v0 == 1 && vl == 1) || (v0 == q0 - 1 && vl == ql - 1));
+        }
+        nz += v0 != 0;
+    }
+    REQUIRE(nz > N * 4 / 10 && nz < N * 6 / 10);
+    ctx.sample_error_polynomial(*s); device_synchronize(); copy_to_host(h.data(), s->coeffs, h.size());
+    double var = 0;
+    for (uint32_t i = 0; i < N; i++) {
+        const uint64_t v0 = h[i].limbs[0], q0 = ctx.params().rns_moduli[0].limbs[0];
+        const double c = v0 > q0 / 2 ? -(double)(q0 - v0) : (double)v0;
+        REQUIRE(c >= -39 && c <= 39);                                       // cut at 12 sigma
+        var += c * c;
+    }
+    var /= N;
+    REQUIRE(var > 3.2 * 3.2 * 0.8 && var < 3.2 * 3.2 * 1.2);
+    PublicKey pk; SecretKey sk; RelinKeys rlk;
+    ctx.keygen(pk, sk);
+    ctx.relinkey_gen(rlk, sk, 16);
+    Plaintext pa, pb, pr;
+    ctx.encode(pa, {5, 10, 15, 20});
+    ctx.encode(pb, {3, 6, 9, 12});
+    Ciphertext ca, cb, csum, cprod;
+    ctx.encrypt(ca, pa, pk); ctx.encrypt(cb, pb, pk);
+    std::vector<uint64_t> out;
+    ctx.add(csum, ca, cb);
+    ctx.decrypt(pr, csum, sk); ctx.decode(out, pr);
+    REQUIRE(out[0] == 8 && out[1] == 16 && out[2] == 24 && out[3] == 32);
+    ctx.multiply(cprod, ca, cb, rlk);
+    ctx.decrypt(pr, cprod, sk); ctx.decode(out, pr);
+    std::cout << "  Multiplication result: " << out[0] << " " << out[1] << " " << out[2] << " " << out[3] << " (expected: 15 60 135 240)" << std::endl;
+    REQUIRE(out[0] == 15 && out[1] == 60 && out[2] == 135 && out[3] == 240);
+    for (size_t i = 4; i < out.size(); i++) REQUIRE(out[i] == 0);
+    delete pk.pk0; delete pk.pk1; delete sk.sk; delete pa.poly; delete pb.poly; delete pr.poly;
+}
+
 // tests/test_fhe.cu:275-318 shape (N = 8192), timing the multiply path instead of encrypt
 static void benchmark_multiply() {
     std::cout << "Benchmark: ciphertext tensor product, N = 8192, log_q = 120" << std::endl;
@@ -306,6 +359,7 @@ int main(int argc, char **argv) {
     test_fhe_multiply();
     test_fhe_multiply_relinearize();
     test_fhe_operations();
+    test_fhe_operations_device_sampling();
     benchmark_multiply();
     std::cout << "ALL PASSED" << std::endl;
     return 0;
