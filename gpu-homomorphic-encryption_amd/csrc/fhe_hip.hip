@@ -238,7 +238,7 @@ static int build_limbs32(fhe_rns_ntt *h, const std::vector<fhe_host::NttConstant
         std::memset(&P, 0, sizeof(P));
         P.q = (uint32_t)q; P.q2 = (uint32_t)(2 * q);
         uint32_t x = 1; for (int i = 0; i < 5; i++) x *= 2 - (uint32_t)q * x;     // q^-1 mod 2^32
-        P.qinv = x;
+        P.qinv = 0u - x;                                                           // negated: F32::mont_mul adds m*q instead of subtracting
         const uint64_t two32 = (1ull << 32) % q, ninv = c.n_inv.w[0], w1 = c.itw[1].w[0];
         auto mulq = [q](uint64_t a, uint64_t b) { return (uint64_t)(((fhe_host::u128)a * b) % q); };
         P.r1 = (uint32_t)two32; P.r1_s = shoup32(two32, q);

@@ -99,11 +99,13 @@ struct F32Base : IntField<Self, uint32_t, TW_> {
     static constexpr int MULT_MINW = 4; // waves per SIMD the fused multiply is compiled for (4 workgroups per CU at N = 8192)
     // x*w mod q for w < q with companion ws = floor(w*2^32/q); any x; result in [0, 2q).
     __device__ static __forceinline__ E shoup_mul(E x, E w, E ws, E q) { return x * w - __umulhi(x, ws) * q; }
-    // a*b*2^-32 mod q, a*b < q*2^32; result in (0, 2q).
-    __device__ static __forceinline__ E mont_mul(E a, E b, E q, E qinv) {
-        uint64_t t = (uint64_t)a * b;
-        E m = (E)t * qinv;
-        return (E)(t >> 32) - __umulhi(m, q) + q;
+    // a*b*2^-32 mod q for a*b < q*2^32; result in [0, 2q).  nqinv = -q^-1 mod 2^32 (Limb::qinv holds the NEGATED inverse on this
+    // field): m = t * nqinv makes t + m*q divisible by 2^32, and the whole reduction is ONE v_mad_u64_u32 (multiply + 64-bit add)
+    // instead of v_mul_hi + v_sub + v_add: 3 multiply-class instructions per product and no additions.  t + m*q < 2 q 2^32 < 2^63.
+    __device__ static __forceinline__ E mont_mul(E a, E b, E q, E nqinv) {
+        const uint64_t t = (uint64_t)a * b;
+        const E m = (E)t * nqinv;
+        return (E)(((uint64_t)m * q + t) >> 32);
     }
     __device__ static __forceinline__ E load_low(const void *container) { return __builtin_nontemporal_load((const E *)container); }
     __device__ static __forceinline__ V16 pack(E v) { V16 o = {v, 0u, 0u, 0u}; return o; }
@@ -216,7 +218,7 @@ struct F52 {
 template <class F>
 struct Limb {
     using E = typename F::E;
-    E q, q2, qinv, _pad0;                 // qinv = q^-1 mod 2^W   (F52: fl(1/q))
+    E q, q2, qinv, _pad0;                 // qinv = q^-1 mod 2^W   (F32: -q^-1 mod 2^32; F52: fl(1/q))
     E r1, r1_s;                           // 2^W mod q             (undo the 2^-W of mont_mul in `pointwise`)
     E ninv, ninv_s;                       // n^-1
     E ninvw, ninvw_s;                     // n^-1 * itw[1]
