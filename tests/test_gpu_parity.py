@@ -850,3 +850,73 @@ def test_negacyclic_reduce_matches_oracle(eng, oracle):
         dD = _up(eng, d)
         eng.negacyclic_reduce(dD, q, n)
         assert np.array_equal(dD.download(d.shape), oracle.negacyclic_reduce(d, q))
+
+
+# ------------------------------------------------------------------------------------ full-size properties, configs[3] / configs[4]
+def test_full_size_properties_config4_ciphertext_multiply(eng, oracle):
+    """BASELINE configs[3] per-GPU shape (N = 16384, 6 limbs, 128 ciphertexts): tensor product + relinearisation.  Size-independent
+    properties (symmetry, a zero c2 leaves the pair untouched, every batch slot equals a batch-1 call) + oracle spot checks."""
+    n, L, batch, w = 16384, 6, 128, 16
+    moduli = nm.ntt_primes(30, n, L)
+    e = eng.RnsNttEngine(n, moduli); rp = oracle.RnsPlan(n, moduli)
+    K = e.relin_num_digits(w)
+    kb, ka = _random_keys(moduli, n, L * K, 31000), _random_keys(moduli, n, L * K, 32000)
+    rk = e.import_relin_keys(w, [_up(eng, k) for k in kb], [_up(eng, k) for k in ka])
+    a0, a1, b0, b1 = (rns_poly(900 + i, moduli, n, batch) for i in range(4))
+    dA0, dA1, dB0, dB1 = (_up(eng, x) for x in (a0, a1, b0, b1))
+    dC = [eng.DeviceBuffer(a0.nbytes) for _ in range(3)]
+    e.ct_multiply(dC[0], dC[1], dC[2], dA0, dA1, dB0, dB1, batch)
+    c = [d.download(a0.shape) for d in dC]
+    dD = [eng.DeviceBuffer(a0.nbytes) for _ in range(3)]
+    e.ct_multiply(dD[0], dD[1], dD[2], dB0, dB1, dA0, dA1, batch)                     # ct(a, b) == ct(b, a)
+    for x, d in zip(c, dD):
+        assert np.array_equal(d.download(a0.shape), x)
+    e.relinearize(rk, dC[0], dC[1], dC[2], batch)
+    r0, r1 = dC[0].download(a0.shape), dC[1].download(a0.shape)
+    dZ = eng.DeviceBuffer(a0.nbytes); dZ.zero()
+    e.relinearize(rk, dD[0], dD[1], dZ, batch)                                        # c2 = 0: nothing to switch
+    assert np.array_equal(dD[0].download(a0.shape), c[0]) and np.array_equal(dD[1].download(a0.shape), c[1])
+    for bi in (0, 77, 127):                                                           # batch slot == batch-1 call == oracle
+        s0, s1, s2 = (_up(eng, np.ascontiguousarray(x[bi:bi + 1])) for x in c)
+        e.relinearize(rk, s0, s1, s2, 1)
+        assert np.array_equal(s0.download((1,) + a0.shape[1:]), r0[bi:bi + 1]) and np.array_equal(s1.download((1,) + a0.shape[1:]), r1[bi:bi + 1])
+    bi = 41
+    w0, w1, w2 = rp.ct_multiply(*(np.ascontiguousarray(x[bi:bi + 1]) for x in (a0, a1, b0, b1)), threads=8)
+    assert all(np.array_equal(x[bi:bi + 1], y) for x, y in zip(c, (w0, w1, w2)))
+    o0, o1 = rp.relinearize(w, w0, w1, w2, kb, ka, threads=8)
+    assert np.array_equal(r0[bi:bi + 1], o0) and np.array_equal(r1[bi:bi + 1], o1)
+    e.check_canonical(dC[0], batch); e.check_canonical(dC[1], batch)
+
+
+def test_full_size_properties_config5_blind_rotation(eng, oracle):
+    """BASELINE configs[4] per-GPU shape (N = 16384, 6 limbs, 128 accumulators, 4 steps): a zero shift is the identity
+    (X^0 - 1 = 0), every batch slot equals a batch-1 call, oracle spot check on one accumulator."""
+    n, L, batch, w, steps = 16384, 6, 128, 16, 4
+    moduli = nm.ntt_primes(30, n, L)
+    e = eng.RnsNttEngine(n, moduli); rp = oracle.RnsPlan(n, moduli)
+    K = e.relin_num_digits(w)
+    rows = [[(_random_keys(moduli, n, L * K, 41000 + 100 * c + 1000 * s), _random_keys(moduli, n, L * K, 42000 + 100 * c + 1000 * s)) for c in range(2)]
+            for s in range(steps)]
+    imported = [[e.import_relin_keys(w, [_up(eng, k) for k in kb], [_up(eng, k) for k in ka]) for kb, ka in r] for r in rows]
+    r0s, r1s = [r[0] for r in imported], [r[1] for r in imported]
+    a0, a1 = rns_poly(951, moduli, n, batch), rns_poly(952, moduli, n, batch)
+    shifts = np.random.default_rng(9).integers(0, 2 * n, size=(steps, batch), dtype=np.uint32)
+    shifts[:, 5] = 0                                                                   # accumulator 5 never rotates
+    dSh = eng.DeviceBuffer.from_numpy(shifts)
+    dA0, dA1 = _up(eng, a0), _up(eng, a1)
+    dT0, dT1 = eng.DeviceBuffer(a0.nbytes), eng.DeviceBuffer(a0.nbytes)
+    e.blind_rotate(r0s, r1s, dA0, dA1, dSh, dT0, dT1, batch)
+    g0, g1 = dA0.download(a0.shape), dA1.download(a0.shape)
+    assert np.array_equal(g0[5], a0[5]) and np.array_equal(g1[5], a1[5])
+    one = (1,) + a0.shape[1:]
+    for bi in (0, 64, 127):
+        s0, s1 = _up(eng, np.ascontiguousarray(a0[bi:bi + 1])), _up(eng, np.ascontiguousarray(a1[bi:bi + 1]))
+        t0, t1 = eng.DeviceBuffer(s0.nbytes), eng.DeviceBuffer(s0.nbytes)
+        dS1 = eng.DeviceBuffer.from_numpy(np.ascontiguousarray(shifts[:, bi:bi + 1]))
+        e.blind_rotate(r0s, r1s, s0, s1, dS1, t0, t1, 1)
+        assert np.array_equal(s0.download(one), g0[bi:bi + 1]) and np.array_equal(s1.download(one), g1[bi:bi + 1])
+    bi = 99
+    w0, w1 = rp.blind_rotate(w, np.ascontiguousarray(a0[bi:bi + 1]), np.ascontiguousarray(a1[bi:bi + 1]), shifts[:, bi:bi + 1],
+                             [r[0] for r in rows], [r[1] for r in rows], threads=8)
+    assert np.array_equal(g0[bi:bi + 1], w0) and np.array_equal(g1[bi:bi + 1], w1)
+    e.check_canonical(dA0, batch); e.check_canonical(dA1, batch)
