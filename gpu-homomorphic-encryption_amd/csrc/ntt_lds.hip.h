@@ -412,12 +412,16 @@ __device__ __forceinline__ void store_from_lds(char *__restrict__ poly, const ty
 // ---- whole-transform building blocks (data in registers, lds = workgroup scratch) ----------------------
 // natural-order coefficients in pattern A  ->  NTT values in pattern Z, in [0, 4q)
 // TWL: the non-uniform stages take their twiddles from `twl`, an LDS copy made by stage_twiddles<F, LOGN, true>.
-template <class F, int LOGN, bool TWL = false>
+// PRESYNC: the barrier that protects the exchange buffer from the PREVIOUS transform's last reads sits here, after the
+// register-only first group, instead of at the end of the caller's loop body: the latest legal place, where it coincides with
+// the transform's own first barrier (a wave that is ahead keeps computing instead of waiting early).
+template <class F, int LOGN, bool TWL = false, bool PRESYNC = false>
 __device__ __forceinline__ void fwd_core(typename F::E (&x)[32], typename F::E *lds, uint32_t tid, const Limb<F> &P,
                                          const typename F::TW *twl = nullptr) {
     using C = NttCfg<LOGN>;
     const typename F::TW *t2 = TWL ? twl : P.tw;
     fwd_stages<F, LOGN, PatA<LOGN>, 4, 0>(x, tid, P.tw, P);
+    if constexpr (PRESYNC) __syncthreads();
     lds_put<PatA<LOGN>>(lds, tid, x);
     __syncthreads();
     lds_get<PatM<LOGN>>(lds, tid, x);
@@ -428,7 +432,7 @@ __device__ __forceinline__ void fwd_core(typename F::E (&x)[32], typename F::E *
     fwd_stages<F, LOGN, PatZ<LOGN>, C::REM - 1, 0, TWL>(x, tid, t2, P);
 }
 // NTT values in pattern Z, in [0, 2q)  ->  coefficients in pattern A, in [0, 2q), scaled by the (ninv..) constants
-template <class F, int LOGN, bool TWL = false>
+template <class F, int LOGN, bool TWL = false, bool PRESYNC = false>
 __device__ __forceinline__ void inv_core(typename F::E (&x)[32], typename F::E *lds, uint32_t tid, const Limb<F> &P,
                                          typename F::E ninv, typename F::E ninv_s, typename F::E ninvw, typename F::E ninvw_s,
                                          const typename F::TW *twl = nullptr) {
@@ -436,6 +440,7 @@ __device__ __forceinline__ void inv_core(typename F::E (&x)[32], typename F::E *
     const typename F::TW *t2 = TWL ? twl : P.itw;
     inv_stages<F, LOGN, PatZ<LOGN>, 0, 4, TWL>(x, tid, t2, P);
     F::regroup(x, P.q, P.qinv);
+    if constexpr (PRESYNC) __syncthreads();
     lds_put<PatZ<LOGN>>(lds, tid, x);
     __syncthreads();
     lds_get<PatY<LOGN>>(lds, tid, x);
@@ -728,7 +733,7 @@ ntt_keyswitch_kernel(char *__restrict__ c0, char *__restrict__ c1, const char *_
             for (uint32_t k = 0; k < K; k++) {
 #pragma unroll
                 for (int r = 0; r < 32; r++) d[r] = F::digit(x[r], k * w, w);
-                fwd_core<F, LOGN, TWL>(d, lds, tid, P, twl);
+                fwd_core<F, LOGN, TWL, true>(d, lds, tid, P, twl);   // PRESYNC: the previous digit's Z-pattern reads are done before this exchange
                 const size_t tbl = ((size_t)(j * K + k) * L + i) * C::N;
                 const VecE *pb = reinterpret_cast<const VecE *>(kb + tbl) + tid, *pa = reinterpret_cast<const VecE *>(ka + tbl) + tid;
 #pragma unroll
@@ -741,12 +746,12 @@ ntt_keyswitch_kernel(char *__restrict__ c0, char *__restrict__ c1, const char *_
                         acc1[r] = F::pw_add(acc1[r], F::pw_mul(va[e], d[r], P.q, P.qinv), P.q, P.q2);
                     }
                 }
-                __syncthreads();                      // every Z-pattern read is done before the next digit's exchange
             }
         }
-        // acc0 -> coefficient domain, + c0   (the last forward transform ended with a barrier: the table can be swapped)
-        if constexpr (TWL) { stage_twiddles<F, LOGN, false>(twl, P.itw, tid); __syncthreads(); }
-        inv_core<F, LOGN, TWL>(acc0, lds, tid, P, P.ninv, P.ninv_s, P.ninvw, P.ninvw_s, twl);
+        // acc0 -> coefficient domain, + c0.  With LDS twiddles every forward-table read must be over before the table is swapped;
+        // otherwise the barrier before the first exchange is inv_core's PRESYNC.
+        if constexpr (TWL) { __syncthreads(); stage_twiddles<F, LOGN, false>(twl, P.itw, tid); __syncthreads(); }
+        inv_core<F, LOGN, TWL, !TWL>(acc0, lds, tid, P, P.ninv, P.ninv_s, P.ninvw, P.ninvw_s, twl);
         load_A<F, LOGN>(c0 + (size_t)p * (C::N * 32), tid, x);
 #pragma unroll
         for (int r = 0; r < 32; r++) acc0[r] = F::ew_add(F::canon_inv(acc0[r], P.q), x[r], P.q);
@@ -773,7 +778,7 @@ ntt_keyswitch_kernel(char *__restrict__ c0, char *__restrict__ c1, const char *_
                 load_A<F, LOGN>(c2 + ((size_t)b * L + j) * (C::N * 32), tid, d);
 #pragma unroll
                 for (int r = 0; r < 32; r++) d[r] = F::digit(d[r], k * w, w);
-                fwd_core<F, LOGN>(d, lds, tid, P);
+                fwd_core<F, LOGN, false, true>(d, lds, tid, P);
                 __builtin_amdgcn_sched_barrier(0);   // keep the 16 key loads (64 VGPRs) from being hoisted into the transform
                 const VecE *pk = reinterpret_cast<const VecE *>(keys + ((size_t)(j * K + k) * L + i) * C::N) + tid;
 #pragma unroll
@@ -785,11 +790,10 @@ ntt_keyswitch_kernel(char *__restrict__ c0, char *__restrict__ c1, const char *_
                         acc[r] = F::pw_add(acc[r], F::pw_mul(v[e], d[r], P.q, P.qinv), P.q, P.q2);
                     }
                 }
-                __syncthreads();
             }
         }
         F::regroup(acc, P.q, P.qinv);              // floating-point sums of L*K products: back below q before the inverse
-        inv_core<F, LOGN>(acc, lds, tid, P, P.ninv, P.ninv_s, P.ninvw, P.ninvw_s);
+        inv_core<F, LOGN, false, true>(acc, lds, tid, P, P.ninv, P.ninv_s, P.ninvw, P.ninvw_s);
         load_A<F, LOGN>(dst + (size_t)p * (C::N * 32), tid, d);
 #pragma unroll
         for (int r = 0; r < 32; r++) acc[r] = F::ew_add(F::canon_inv(acc[r], P.q), d[r], P.q);
@@ -814,7 +818,8 @@ __device__ __forceinline__ void load_monomial_A(const char *__restrict__ poly, t
     using C = NttCfg<LOGN>;
     using E = typename F::E;
     load_A<F, LOGN>(poly, tid, x);                  // p[i], i = tid + r*T
-    lds_put<PatA<LOGN>>(lds, tid, x);               // the caller guarantees that nobody still reads the exchange buffer
+    __syncthreads();                                // the previous transform's last reads of the exchange buffer are over
+    lds_put<PatA<LOGN>>(lds, tid, x);
     __syncthreads();
     const uint32_t k0 = tid + 2 * C::N - a;
 #pragma unroll
@@ -857,7 +862,7 @@ ntt_extprod_kernel(char *__restrict__ out0, char *__restrict__ out1, const char 
         E acc0[32], acc1[32], x[32], d[32];
 #pragma unroll
         for (int r = 0; r < 32; r++) { acc0[r] = 0; acc1[r] = 0; }
-        if constexpr (TWL) stage_twiddles<F, LOGN, true>(twl, P.tw, tid);     // visible after the barrier inside load_monomial_A
+        if constexpr (TWL) stage_twiddles<F, LOGN, true>(twl, P.tw, tid);     // visible after the barriers inside load_monomial_A
         for (uint32_t c = 0; c < 2; c++) {
             const char *src = c ? in1 : in0;
             const E *kb = c ? kb1 : kb0, *ka = c ? ka1 : ka0;
@@ -866,7 +871,7 @@ ntt_extprod_kernel(char *__restrict__ out0, char *__restrict__ out1, const char 
                 for (uint32_t k = 0; k < K; k++) {
 #pragma unroll
                     for (int r = 0; r < 32; r++) d[r] = F::digit(x[r], k * w, w);
-                    fwd_core<F, LOGN, TWL>(d, lds, tid, P, twl);
+                    fwd_core<F, LOGN, TWL, true>(d, lds, tid, P, twl);
                     const size_t tbl = ((size_t)(j * K + k) * L + i) * C::N;
                     const VecE *pb = reinterpret_cast<const VecE *>(kb + tbl) + tid, *pa = reinterpret_cast<const VecE *>(ka + tbl) + tid;
 #pragma unroll
@@ -879,12 +884,11 @@ ntt_extprod_kernel(char *__restrict__ out0, char *__restrict__ out1, const char 
                             acc1[r] = F::pw_add(acc1[r], F::pw_mul(va[e], d[r], P.q, P.qinv), P.q, P.q2);
                         }
                     }
-                    __syncthreads();
                 }
             }
         }
-        if constexpr (TWL) { stage_twiddles<F, LOGN, false>(twl, P.itw, tid); __syncthreads(); }
-        inv_core<F, LOGN, TWL>(acc0, lds, tid, P, P.ninv, P.ninv_s, P.ninvw, P.ninvw_s, twl);
+        if constexpr (TWL) { __syncthreads(); stage_twiddles<F, LOGN, false>(twl, P.itw, tid); __syncthreads(); }
+        inv_core<F, LOGN, TWL, !TWL>(acc0, lds, tid, P, P.ninv, P.ninv_s, P.ninvw, P.ninvw_s, twl);
         load_A<F, LOGN>(in0 + (size_t)p * (C::N * 32), tid, x);
 #pragma unroll
         for (int r = 0; r < 32; r++) acc0[r] = F::ew_add(F::canon_inv(acc0[r], P.q), x[r], P.q);
@@ -912,7 +916,7 @@ ntt_extprod_kernel(char *__restrict__ out0, char *__restrict__ out1, const char 
                     load_monomial_A<F, LOGN>(src + ((size_t)b * L + j) * (C::N * 32), lds, tid, a, qj, d);
 #pragma unroll
                     for (int r = 0; r < 32; r++) d[r] = F::digit(d[r], k * w, w);
-                    fwd_core<F, LOGN>(d, lds, tid, P);
+                    fwd_core<F, LOGN, false, true>(d, lds, tid, P);
                     __builtin_amdgcn_sched_barrier(0);
                     const VecE *pk = reinterpret_cast<const VecE *>(keys + ((size_t)(j * K + k) * L + i) * C::N) + tid;
 #pragma unroll
@@ -924,12 +928,11 @@ ntt_extprod_kernel(char *__restrict__ out0, char *__restrict__ out1, const char 
                             acc[r] = F::pw_add(acc[r], F::pw_mul(v[e], d[r], P.q, P.qinv), P.q, P.q2);
                         }
                     }
-                    __syncthreads();
                 }
             }
             F::regroup(acc, P.q, P.qinv);          // floating-point sums of L*K products: back below q (no-op for the integer fields)
         }
-        inv_core<F, LOGN>(acc, lds, tid, P, P.ninv, P.ninv_s, P.ninvw, P.ninvw_s);
+        inv_core<F, LOGN, false, true>(acc, lds, tid, P, P.ninv, P.ninv_s, P.ninvw, P.ninvw_s);
         load_A<F, LOGN>((half ? in1 : in0) + (size_t)p * (C::N * 32), tid, d);
 #pragma unroll
         for (int r = 0; r < 32; r++) acc[r] = F::ew_add(F::canon_inv(acc[r], P.q), d[r], P.q);

@@ -22,7 +22,7 @@ static Limb<F32> *build_m(uint32_t n, uint32_t L) {
         std::vector<uint32_t> tw(n), itw(n);
         for (uint32_t k = 0; k < n; k++) { tw[k] = (uint32_t)((c.tw[k].w[0] << 32) % q); itw[k] = (uint32_t)((c.itw[k].w[0] << 32) % q); }
         Limb<F32> &P = limbs[l]; memset(&P, 0, sizeof P);
-        P.q = q; P.q2 = 2 * q; uint32_t x = 1; for (int i = 0; i < 5; i++) x *= 2 - (uint32_t)q * x; P.qinv = x;
+        P.q = q; P.q2 = 2 * q; uint32_t x = 1; for (int i = 0; i < 5; i++) x *= 2 - (uint32_t)q * x; P.qinv = 0u - x;   /* F32::mont_mul wants -q^-1 */
         auto mulq = [q](uint64_t a, uint64_t b) { return (uint64_t)(((unsigned __int128)a * b) % q); };
         uint64_t two32 = (1ull << 32) % q, ninv = c.n_inv.w[0], w1 = c.itw[1].w[0], nw = mulq(ninv, w1);
         P.r1 = two32; P.r1_s = shoup32(two32, q); P.ninv = ninv; P.ninv_s = shoup32(ninv, q); P.ninvw = nw; P.ninvw_s = shoup32(nw, q);
