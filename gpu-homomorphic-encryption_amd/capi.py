@@ -79,6 +79,8 @@ def lib():
         "fhe_blind_rotate_step": ([vp, vp, vp, vp, vp, vp, vp, vp, u32], ci),
         "fhe_blind_rotate": ([vp, P(vp), P(vp), u32, vp, vp, vp, vp, vp, u32], ci),
         "fhe_rns_fast_base_convert": ([vp, vp, vp, vp, u32], ci),
+        "fhe_ref_forward_kernel_literal": ([vp, vp, U64x4, u64, u32, u32, vp], ci),
+        "fhe_ref_inverse_kernel_literal": ([vp, vp, U64x4, u64, U64x4, u32, u32, vp], ci),
         "fhe_sample_uniform_lcg": ([vp, U64x4, u64, sz, vp], ci),
         "fhe_sample_gaussian_placeholder": ([vp, U64x4, u64, sz, vp], ci),
         "fhe_rns_sample_ternary": ([vp, vp, ctypes.c_double, u64, u32], ci),
@@ -199,6 +201,14 @@ def _ptr(x):
 
 
 # ---- literal element-wise primitives ----------------------------------------------------------------
+def ref_forward_kernel_literal(data, twiddles, q, inv0, n, batch=1, stream=None):
+    _check(lib().fhe_ref_forward_kernel_literal(_ptr(data), _ptr(twiddles), _q4(q), inv0, n, batch, stream))
+
+
+def ref_inverse_kernel_literal(data, inv_twiddles, q, inv0, n_inv, n, batch=1, stream=None):
+    _check(lib().fhe_ref_inverse_kernel_literal(_ptr(data), _ptr(inv_twiddles), _q4(q), inv0, _q4(n_inv), n, batch, stream))
+
+
 def sample_uniform_lcg(out, q, seed, count, stream=None):
     _check(lib().fhe_sample_uniform_lcg(_ptr(out), _q4(q), seed, count, stream))
 

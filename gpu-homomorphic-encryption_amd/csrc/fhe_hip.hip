@@ -178,6 +178,30 @@ extern "C" int fhe_u256_mont_mul_scalar(void *r, const void *a, const uint64_t s
     return launch_ew256<3>(r, a, nullptr, q, scalar, inv0, count, stream, "fhe_u256_mont_mul_scalar");
 }
 
+// the reference's transform kernels as written (L1 parity; see ntt256.hip.h)
+static int ref_literal_check(const void *d_data, const void *d_table, const uint64_t q[4], uint32_t n, uint32_t batch, const char *what) {
+    if (!d_data || !d_table || !q) return fail(FHE_ERR_INVALID_ARG, std::string(what) + ": null argument");
+    if (n < 2 || (n & (n - 1)) || n > 65536) return fail(FHE_ERR_INVALID_ARG, std::string(what) + ": n must be a power of two in [2, 65536]");
+    if (!batch) return fail(FHE_ERR_INVALID_ARG, std::string(what) + ": batch must be >= 1");
+    return ensure_device();
+}
+extern "C" int fhe_ref_forward_kernel_literal(void *d_data, const void *d_twiddles, const uint64_t q[4], uint64_t inv0, uint32_t n, uint32_t batch, void *stream) {
+    int rc = ref_literal_check(d_data, d_twiddles, q, n, batch, "fhe_ref_forward_kernel_literal"); if (rc) return rc;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(fhe_dev::ref_forward_literal_kernel, dim3(batch), dim3(256), 0, (hipStream_t)stream, (fhe_dev::u256 *)d_data,
+                       (const fhe_dev::u256 *)d_twiddles, to_dev(q), inv0, n);
+    return post_launch((hipStream_t)stream, "ref_forward_literal_kernel");
+}
+extern "C" int fhe_ref_inverse_kernel_literal(void *d_data, const void *d_inv_twiddles, const uint64_t q[4], uint64_t inv0, const uint64_t n_inv[4],
+                                              uint32_t n, uint32_t batch, void *stream) {
+    int rc = ref_literal_check(d_data, d_inv_twiddles, q, n, batch, "fhe_ref_inverse_kernel_literal"); if (rc) return rc;
+    if (!n_inv) return fail(FHE_ERR_INVALID_ARG, "fhe_ref_inverse_kernel_literal: n_inv is null");
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(fhe_dev::ref_inverse_literal_kernel, dim3(batch), dim3(256), 0, (hipStream_t)stream, (fhe_dev::u256 *)d_data,
+                       (const fhe_dev::u256 *)d_inv_twiddles, to_dev(q), inv0, to_dev(n_inv), n);
+    return post_launch((hipStream_t)stream, "ref_inverse_literal_kernel");
+}
+
 // ------------------------------------------------------------------------------------------------------
 // engine handle
 // ------------------------------------------------------------------------------------------------------

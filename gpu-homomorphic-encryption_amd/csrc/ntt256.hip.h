@@ -302,6 +302,55 @@ fast_base_convert_kernel(u256 *__restrict__ out, const u256 *__restrict__ in, co
     }
 }
 
+// ---- the reference's transform kernels AS WRITTEN (L1 parity) ---------------------------------------------------------
+// ntt_forward_optimized_kernel / ntt_inverse_optimized_kernel (kernels/ntt_kernels.cu:7-62, :65-121), launched by
+// NTTEngine::forward / inverse as ONE block of n threads (src/ntt.cu:30-47): stage schedule with log_n = popc(n-1)+1 (sic),
+// butterfly pairs (k*2m + j, k*2m + j + m) only where the second index < block size (= n), twiddle index j << (log_n-stage-1),
+// caller-supplied tables (the reference fills them with placeholders, src/ntt.cu:86-97), literal mul_mod_montgomery /
+// add_mod / sub_mod.  The n "threads" of the reference's block are walked by the lanes of one workgroup (within a stage every
+// thread owns a private pair, so the order inside a stage is irrelevant); the data stay in device memory instead of the
+// reference's dynamic shared memory (n * 32 bytes: beyond any LDS for n > 4096), which changes nothing observable.
+// One workgroup per polynomial of a [batch][n] buffer.  bit_reverse_kernel is not applied (out-of-bounds accesses there make
+// its result undefined); these kernels are what the reference's own source computes on the data it is given.
+__global__ void __launch_bounds__(256)
+ref_forward_literal_kernel(u256 *__restrict__ data, const u256 *__restrict__ tw, u256 q, uint64_t inv0, uint32_t n) {
+    u256 *d = data + (size_t)blockIdx.x * n;
+    const uint32_t log_n = (uint32_t)__popc(n - 1) + 1;
+    for (uint32_t stage = 0; stage < log_n; stage++) {
+        const uint32_t m = 1u << stage, m2 = m << 1;
+        for (uint32_t tid = threadIdx.x; tid < n; tid += blockDim.x) {
+            const uint32_t k = tid / m, j = tid % m;
+            if ((uint64_t)k * m2 + j + m < n) {
+                const uint32_t idx1 = k * m2 + j, idx2 = idx1 + m;
+                const u256 u = load_u256(d + idx1);
+                const u256 v = mont_mul(load_u256(d + idx2), load_u256(tw + (j << (log_n - stage - 1))), q, inv0);
+                store_u256(d + idx1, add_mod(u, v, q));
+                store_u256(d + idx2, sub_mod(u, v, q));
+            }
+        }
+        __syncthreads();
+    }
+}
+__global__ void __launch_bounds__(256)
+ref_inverse_literal_kernel(u256 *__restrict__ data, const u256 *__restrict__ itw, u256 q, uint64_t inv0, u256 n_inv, uint32_t n) {
+    u256 *d = data + (size_t)blockIdx.x * n;
+    const uint32_t log_n = (uint32_t)__popc(n - 1) + 1;
+    for (int stage = (int)log_n - 1; stage >= 0; stage--) {
+        const uint32_t m = 1u << stage, m2 = m << 1;
+        for (uint32_t tid = threadIdx.x; tid < n; tid += blockDim.x) {
+            const uint32_t k = tid / m, j = tid % m;
+            if ((uint64_t)k * m2 + j + m < n) {
+                const uint32_t idx1 = k * m2 + j, idx2 = idx1 + m;
+                const u256 u = load_u256(d + idx1), v = load_u256(d + idx2);
+                store_u256(d + idx1, add_mod(u, v, q));
+                store_u256(d + idx2, mont_mul(sub_mod(u, v, q), load_u256(itw + (j << (log_n - (uint32_t)stage - 1))), q, inv0));
+            }
+        }
+        __syncthreads();
+    }
+    for (uint32_t tid = threadIdx.x; tid < n; tid += blockDim.x) store_u256(d + tid, mont_mul(load_u256(d + tid), n_inv, q, inv0));
+}
+
 // (X^shift[b] - 1) * p on full-width containers (see monomial_mul_sub_kernel in ntt_lds.hip.h)
 __global__ void __launch_bounds__(256)
 monomial_mul_sub256_kernel(u256 *__restrict__ out, const u256 *__restrict__ in, const uint32_t *__restrict__ shifts,

@@ -97,6 +97,19 @@ int fhe_u256_mont_mul(void *d_r, const void *d_a, const void *d_b, const uint64_
 /* poly_mul_scalar_kernel (src/polynomial.cu:98-111): r[i] = mul_mod_montgomery(a[i], scalar, q, inv). */
 int fhe_u256_mont_mul_scalar(void *d_r, const void *d_a, const uint64_t scalar[4], const uint64_t q[4], uint64_t inv0, size_t count, void *stream);
 
+/* ---- the reference's transform kernels AS WRITTEN (L1 parity) ---------------------------------------------- */
+/* ntt_forward_optimized_kernel (kernels/ntt_kernels.cu:7-62) exactly as NTTEngine::forward launches it (one block of n threads,
+ * src/ntt.cu:30-40, WITHOUT the out-of-bounds bit_reverse_kernel): stage schedule log_n = popc(n-1)+1, pairs
+ * (k*2m + j, k*2m + j + m) where the second index < n, twiddle index j << (log_n - stage - 1), caller-supplied table of n
+ * containers (the reference fills it with the placeholders [1, 1, 2, 3, ...], src/ntt.cu:86-97), literal primitives.  This is
+ * what the reference's source computes on the data it is given -- not an NTT with those tables; fhe_ntt_forward is the real
+ * transform.  [batch][n] polynomials, one workgroup each; n a power of two up to 65536 (the reference itself cannot launch n > 1024). */
+int fhe_ref_forward_kernel_literal(void *d_data, const void *d_twiddles, const uint64_t q[4], uint64_t inv0, uint32_t n, uint32_t batch, void *stream);
+/* ntt_inverse_optimized_kernel (kernels/ntt_kernels.cu:65-121): the same pairs in reverse stage order, Gentleman-Sande form,
+ * then every element mont(x, n_inv). */
+int fhe_ref_inverse_kernel_literal(void *d_data, const void *d_inv_twiddles, const uint64_t q[4], uint64_t inv0, const uint64_t n_inv[4],
+                                   uint32_t n, uint32_t batch, void *stream);
+
 /* ---- single-modulus engine: fhe::NTTEngine -------------------------------------------------- */
 /* NTTEngine::NTTEngine(n, modulus) (src/ntt.cu:7-22) + precompute_twiddle_factors (:77-107), with the
  * root / inverse / table placeholders replaced by real values.  q prime, q = 1 (mod 2n), q < 2^255,

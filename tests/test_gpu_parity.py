@@ -920,3 +920,67 @@ def test_full_size_properties_config5_blind_rotation(eng, oracle):
                              [r[0] for r in rows], [r[1] for r in rows], threads=8)
     assert np.array_equal(g0[bi:bi + 1], w0) and np.array_equal(g1[bi:bi + 1], w1)
     e.check_canonical(dA0, batch); e.check_canonical(dA1, batch)
+
+
+# ------------------------------------------------------------------------------------ L1: the reference's transform kernels as written
+def test_reference_literal_kernels_reproduce_survey_kats_on_gpu(eng, oracle, golden_dir):
+    """outputs of the reference's OWN kernel source (ntt_forward_optimized_kernel / ntt_inverse_optimized_kernel
+    with the placeholder tables src/ntt.cu:86-97 builds, data x[i] = i + 1, q = 12289) -- reproduced on the GPU through the ABI."""
+    import json
+    kats = json.load(open(os.path.join(golden_dir, "reference_kats.json")))
+    for c in kats["survey_appendix_b"]["literal_kernels_placeholder_tables"]:
+        n, q = c["n"], int(c["q"])
+        tw = oracle.ref_placeholder_table(n)
+        x = oracle.to_limbs(range(1, n + 1))
+        dX, dT = _up(eng, x), _up(eng, tw)
+        inv0 = oracle.mont_inverse(q)
+        eng.ref_forward_kernel_literal(dX, dT, q, inv0, n)
+        f = dX.download(x.shape)
+        assert oracle.from_limbs(f)[:8] == c["forward_first8"]
+        assert np.array_equal(f, oracle.ref_forward_kernel(x, tw, q))
+        eng.ref_inverse_kernel_literal(dX, dT, q, inv0, int(c["n_inv"]), n)
+        i = dX.download(x.shape)
+        assert oracle.from_limbs(i)[:8] == c["then_inverse_first8"]
+        assert np.array_equal(i, oracle.ref_inverse_kernel(f, tw, q, int(c["n_inv"])))
+
+
+@pytest.mark.parametrize("n,q", [(2, 12289), (8, 40961), (64, 12289), (1024, "p60"), (4096, "wide"), (256, 1 << 60)])
+def test_reference_literal_kernels_match_oracle(eng, oracle, n, q):
+    """Arbitrary tables and data (incl. unreduced values and the even modulus 2^60 the reference really passes): literal, batched."""
+    if q == "p60":
+        q = nm.ntt_primes(60, 8192, 1)[0]
+    elif q == "wide":
+        q = nm.ntt_primes(250, 4096, 1)[0]
+    rng = random.Random(n)
+    batch = 3
+    data = oracle.to_limbs([rng.getrandbits(256) if i % 7 == 0 else rng.randrange(q) for i in range(batch * n)])
+    tw = oracle.to_limbs([rng.randrange(q) for _ in range(n)])
+    n_inv = rng.randrange(q)
+    inv0 = oracle.mont_inverse(q)
+    dD, dT = _up(eng, data), _up(eng, tw)
+    eng.ref_forward_kernel_literal(dD, dT, q, inv0, n, batch)
+    f = dD.download(data.shape)
+    want_f = np.concatenate([oracle.ref_forward_kernel(np.ascontiguousarray(data[b * n:(b + 1) * n]), tw, q) for b in range(batch)])
+    assert np.array_equal(f, want_f)
+    eng.ref_inverse_kernel_literal(dD, dT, q, inv0, n_inv, n, batch)
+    want_i = np.concatenate([oracle.ref_inverse_kernel(np.ascontiguousarray(want_f[b * n:(b + 1) * n]), tw, q, n_inv) for b in range(batch)])
+    assert np.array_equal(dD.download(data.shape), want_i)
+
+
+def test_reference_literal_kernels_with_real_tables_are_the_cyclic_dft(eng, oracle):
+    """SURVEY D3/D4 on the device: with tw[k] = psi^k * R the reference's forward kernel is the cyclic DFT (omega = psi^2) of the
+    bit-reversed input and its inverse kernel undoes it -- the reading of the reference under which it is a transform at all."""
+    q, n = 12289, 64
+    psi = nm.find_psi(n, q); Rm = nm.R % q
+    tw = oracle.to_limbs([pow(psi, k, q) * Rm % q for k in range(n)])
+    itw = oracle.to_limbs([pow(psi, -k, q) * Rm % q for k in range(n)])
+    n_inv_m = pow(n, -1, q) * Rm % q
+    rng = random.Random(1)
+    x = [rng.randrange(q) for _ in range(n)]
+    xb = [x[nm.bitrev(i, 6)] for i in range(n)]
+    dX = _up(eng, oracle.to_limbs(xb)); inv0 = oracle.mont_inverse(q)
+    eng.ref_forward_kernel_literal(dX, _up(eng, tw), q, inv0, n)
+    om = psi * psi % q
+    assert oracle.from_limbs(dX.download((n, 4))) == [sum(x[j] * pow(om, j * k, q) for j in range(n)) % q for k in range(n)]
+    eng.ref_inverse_kernel_literal(dX, _up(eng, itw), q, inv0, n_inv_m, n)
+    assert oracle.from_limbs(dX.download((n, 4))) in (xb, x)
