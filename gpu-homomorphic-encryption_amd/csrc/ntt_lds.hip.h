@@ -70,9 +70,9 @@ struct IntField {
     __device__ static __forceinline__ E regroup1(E x, E, E) { return x; }
     __device__ static __forceinline__ E canon_fwd(E x, E q, E q2, E) { return csub<E>(csub<E>(x, q2), q); }   // [0,4q) -> [0,q)
     __device__ static __forceinline__ E canon_inv(E x, E q) { return csub<E>(x, q); }       // [0,2q) -> [0,q)
-    // NTT-domain product for the fused kernels: a canonical, b lazy (< 4q); result in (0,2q), carries 2^-W
+    // NTT-domain product for the fused kernels: a canonical, b lazy (< 4q); result in [0,2q), carries 2^-W
     __device__ static __forceinline__ E pw_mul(E a, E b, E q, E qinv) { return Self::mont_mul(a, b, q, qinv); }
-    // (0,2q)+(0,2q) -> [0,2q)
+    // [0,2q)+[0,2q) -> [0,2q)
     __device__ static __forceinline__ E pw_add(E a, E b, E, E q2) { return csub<E>(a + b, q2); }
     // element-wise canonical ops
     template <class L> __device__ static __forceinline__ E ew_mul(E x, E y, const L &P) {
@@ -518,7 +518,7 @@ ntt_multiply_kernel(char *res, const char *a, const char *b,      // no __restri
     __syncthreads();                       // all Z-pattern reads of a are done before b overwrites the slots
     fwd_core<F, LOGN>(y, lds, tid, P);
 #pragma unroll
-    for (int r = 0; r < 32; r++) x[r] = F::pw_mul(x[r], y[r], P.q, P.qinv);   // (0,2q), carries 2^-W
+    for (int r = 0; r < 32; r++) x[r] = F::pw_mul(x[r], y[r], P.q, P.qinv);   // [0,2q), carries 2^-W
     inv_core<F, LOGN>(x, lds, tid, P, P.ninv_r, P.ninv_r_s, P.ninvw_r, P.ninvw_r_s);
 #pragma unroll
     for (int r = 0; r < 32; r++) x[r] = F::canon_inv(x[r], P.q);
@@ -602,7 +602,7 @@ ntt_ct_multiply_kernel(char *__restrict__ c0, char *__restrict__ c1, char *__res
         E t01 = F::pw_mul(u0, v1, P.q, P.qinv);
         E t10 = F::pw_mul(u1, v0, P.q, P.qinv);
         E t11 = F::pw_mul(u1, v1, P.q, P.qinv);
-        A0[r] = t00;                           // (0,2q)
+        A0[r] = t00;                           // [0,2q)
         A1[r] = F::pw_add(t01, t10, P.q, P.q2);   // (0,4q) -> [0,2q)
         B0[r] = t11;
     }
@@ -942,7 +942,7 @@ ntt_extprod_kernel(char *__restrict__ out0, char *__restrict__ out1, const char 
     }
 }
 
-// ---- relinearisation building blocks (general path; the fused key-switch kernel for F32 is below) --------------------
+// ---- relinearisation building blocks (general path; the fused key-switch kernels are above) --------------------
 // Digit polynomials of c2 embedded in every limb: D[jk][b][i][x] = ((c2[b][j][x] >> (k*w)) & (2^w - 1)) mod q_i,
 // jk = j*K + k.  One 16-byte half container per lane.
 template <class F>
