@@ -81,6 +81,7 @@ def lib():
         "fhe_rns_fast_base_convert": ([vp, vp, vp, vp, u32], ci),
         "fhe_ref_forward_kernel_literal": ([vp, vp, U64x4, u64, u32, u32, vp], ci),
         "fhe_ref_inverse_kernel_literal": ([vp, vp, U64x4, u64, U64x4, u32, u32, vp], ci),
+        "fhe_ref_stockham_stage_literal": ([vp, vp, vp, U64x4, u64, u32, u32, u32, vp], ci),
         "fhe_sample_uniform_lcg": ([vp, U64x4, u64, sz, vp], ci),
         "fhe_sample_gaussian_placeholder": ([vp, U64x4, u64, sz, vp], ci),
         "fhe_rns_sample_ternary": ([vp, vp, ctypes.c_double, u64, u32], ci),
@@ -207,6 +208,10 @@ def ref_forward_kernel_literal(data, twiddles, q, inv0, n, batch=1, stream=None)
 
 def ref_inverse_kernel_literal(data, inv_twiddles, q, inv0, n_inv, n, batch=1, stream=None):
     _check(lib().fhe_ref_inverse_kernel_literal(_ptr(data), _ptr(inv_twiddles), _q4(q), inv0, _q4(n_inv), n, batch, stream))
+
+
+def ref_stockham_stage_literal(output, data, twiddles, q, inv0, n, stage, batch=1, stream=None):
+    _check(lib().fhe_ref_stockham_stage_literal(_ptr(output), _ptr(data), _ptr(twiddles), _q4(q), inv0, n, stage, batch, stream))
 
 
 def sample_uniform_lcg(out, q, seed, count, stream=None):

@@ -202,6 +202,18 @@ extern "C" int fhe_ref_inverse_kernel_literal(void *d_data, const void *d_inv_tw
     return post_launch((hipStream_t)stream, "ref_inverse_literal_kernel");
 }
 
+extern "C" int fhe_ref_stockham_stage_literal(void *d_output, const void *d_input, const void *d_twiddles, const uint64_t q[4], uint64_t inv0, uint32_t n,
+                                             uint32_t stage, uint32_t batch, void *stream) {
+    int rc = ref_literal_check(d_output, d_twiddles, q, n, batch, "fhe_ref_stockham_stage_literal"); if (rc) return rc;
+    if (!d_input || d_input == d_output) return fail(FHE_ERR_INVALID_ARG, "fhe_ref_stockham_stage_literal: the stage is out of place");
+    if ((2u << stage) > n) return fail(FHE_ERR_INVALID_ARG, "fhe_ref_stockham_stage_literal: stage must satisfy 2^(stage+1) <= n");
+    (void)hipGetLastError();
+    const size_t count = (size_t)batch * (n / 2);
+    hipLaunchKernelGGL(fhe_dev::ref_stockham_stage_kernel, dim3(ew_grid(count)), dim3(256), 0, (hipStream_t)stream, (fhe_dev::u256 *)d_output,
+                       (const fhe_dev::u256 *)d_input, (const fhe_dev::u256 *)d_twiddles, to_dev(q), inv0, n, stage, count);
+    return post_launch((hipStream_t)stream, "ref_stockham_stage_kernel");
+}
+
 // ------------------------------------------------------------------------------------------------------
 // engine handle
 // ------------------------------------------------------------------------------------------------------

@@ -351,6 +351,26 @@ ref_inverse_literal_kernel(u256 *__restrict__ data, const u256 *__restrict__ itw
     for (uint32_t tid = threadIdx.x; tid < n; tid += blockDim.x) store_u256(d + tid, mont_mul(load_u256(d + tid), n_inv, q, inv0));
 }
 
+// ntt_stockham_kernel (kernels/ntt_kernels.cu:213-243; never launched by the reference): ONE out-of-place butterfly stage,
+// output[idx1] = input[idx1] + mont(input[idx2], tw[j * (n / 2m)]), output[idx2] = input[idx1] - ..., idx1 = k*2m + j, idx2 = idx1 + m.
+// As written the kernel runs idx over [0, n) and indexes past the arrays for idx >= n/2 (undefined); this restatement runs the
+// n/2 in-bounds butterflies, which are all of a stage.  One lane per butterfly, [batch][n] polynomials.
+__global__ void __launch_bounds__(256)
+ref_stockham_stage_kernel(u256 *__restrict__ output, const u256 *__restrict__ input, const u256 *__restrict__ tw, u256 q, uint64_t inv0,
+                          uint32_t n, uint32_t stage, size_t count /* batch * n/2 */) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const uint32_t m = 1u << stage, m2 = m << 1, half = n >> 1;
+    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < count; g += stride) {
+        const size_t b = g / half; const uint32_t idx = (uint32_t)(g % half);
+        const uint32_t k = idx / m, j = idx % m, idx1 = k * m2 + j, idx2 = idx1 + m;
+        const u256 *in = input + b * n; u256 *out = output + b * n;
+        const u256 u = load_u256(in + idx1);
+        const u256 v = mont_mul(load_u256(in + idx2), load_u256(tw + j * (n / m2)), q, inv0);
+        store_u256(out + idx1, add_mod(u, v, q));
+        store_u256(out + idx2, sub_mod(u, v, q));
+    }
+}
+
 // (X^shift[b] - 1) * p on full-width containers (see monomial_mul_sub_kernel in ntt_lds.hip.h)
 __global__ void __launch_bounds__(256)
 monomial_mul_sub256_kernel(u256 *__restrict__ out, const u256 *__restrict__ in, const uint32_t *__restrict__ shifts,

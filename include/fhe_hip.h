@@ -110,6 +110,12 @@ int fhe_ref_forward_kernel_literal(void *d_data, const void *d_twiddles, const u
 int fhe_ref_inverse_kernel_literal(void *d_data, const void *d_inv_twiddles, const uint64_t q[4], uint64_t inv0, const uint64_t n_inv[4],
                                    uint32_t n, uint32_t batch, void *stream);
 
+/* ntt_stockham_kernel (kernels/ntt_kernels.cu:213-243, never launched by the reference): one out-of-place butterfly stage,
+ * out[i1] = in[i1] + mont(in[i2], tw[j * n / 2m]), out[i2] = in[i1] - ..., i1 = k*2m + j, i2 = i1 + m, m = 2^stage.  The n/2
+ * in-bounds butterflies are run (as written the kernel also indexes past the arrays for idx >= n/2: undefined). */
+int fhe_ref_stockham_stage_literal(void *d_output, const void *d_input, const void *d_twiddles, const uint64_t q[4], uint64_t inv0, uint32_t n,
+                                   uint32_t stage, uint32_t batch, void *stream);
+
 /* ---- single-modulus engine: fhe::NTTEngine -------------------------------------------------- */
 /* NTTEngine::NTTEngine(n, modulus) (src/ntt.cu:7-22) + precompute_twiddle_factors (:77-107), with the
  * root / inverse / table placeholders replaced by real values.  q prime, q = 1 (mod 2n), q < 2^255,

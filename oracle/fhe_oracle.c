@@ -170,6 +170,19 @@ void orc_ref_pointwise_kernel(orc_u256 *r, const orc_u256 *a, const orc_u256 *b,
     for (uint32_t i = 0; i < n; i++) orc_mont_mul(&r[i], &a[i], &b[i], q, inv0);
 }
 
+/* ntt_stockham_kernel (kernels/ntt_kernels.cu:213-243), the n/2 in-bounds butterflies of one out-of-place stage. */
+void orc_ref_stockham_stage(orc_u256 *output, const orc_u256 *input, const orc_u256 *tw, const orc_u256 *q, uint64_t inv0, uint32_t n, uint32_t stage) {
+    uint32_t m = 1u << stage, m2 = m << 1;
+    for (uint32_t idx = 0; idx < n / 2; idx++) {
+        uint32_t k = idx / m, j = idx % m, idx1 = k * m2 + j, idx2 = idx1 + m;
+        uint32_t tw_idx = j * (n / m2);
+        orc_u256 u = input[idx1], v;
+        orc_mont_mul(&v, &input[idx2], &tw[tw_idx], q, inv0);
+        orc_add_mod(&output[idx1], &u, &v, q);
+        orc_sub_mod(&output[idx2], &u, &v, q);
+    }
+}
+
 void orc_ref_placeholder_table(orc_u256 *tw, uint32_t n) {
     memset(tw, 0, (size_t)n * sizeof(orc_u256));
     tw[0].limbs[0] = 1;                                      /* src/ntt.cu:86,93 */

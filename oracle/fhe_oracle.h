@@ -59,6 +59,7 @@ void orc_ref_inverse_kernel(orc_u256 *data, const orc_u256 *itw, const orc_u256 
 void orc_ref_pointwise_kernel(orc_u256 *r, const orc_u256 *a, const orc_u256 *b, const orc_u256 *q,
                               uint64_t inv0, uint32_t n);
 /* src/ntt.cu:86-97 : the placeholder tables the reference really builds: [1,1,2,...,n-1] */
+void orc_ref_stockham_stage(orc_u256 *output, const orc_u256 *input, const orc_u256 *tw, const orc_u256 *q, uint64_t inv0, uint32_t n, uint32_t stage);
 void orc_ref_placeholder_table(orc_u256 *tw, uint32_t n);
 
 /* ---- L2: the intended mathematics (negacyclic NTT over x^n+1), built ONLY from the L0 primitives --- */

@@ -57,6 +57,7 @@ def lib():
             "orc_ref_inverse_kernel": (None, [P, P, P, u64, P, u32]),
             "orc_ref_pointwise_kernel": (None, [P, P, P, P, u64, u32]),
             "orc_ref_placeholder_table": (None, [P, u32]),
+            "orc_ref_stockham_stage": (None, [P, P, P, P, u64, u32, u32]),
             "orc_plan_create": (vp, [u32, P]),
             "orc_plan_destroy": (None, [vp]),
             "orc_plan_psi": (None, [vp, P]),
@@ -204,6 +205,14 @@ def ref_inverse_kernel(data, itw, q, n_inv, inv0=None):
         inv0 = mont_inverse(q)
     _chk(data, itw); d = data.copy(); Q, NI = _one(q), _one(n_inv)
     lib().orc_ref_inverse_kernel(_p(d), _p(itw), _p(Q), inv0, _p(NI), d.shape[0]); return d
+
+
+def ref_stockham_stage(data, tw, q, stage, inv0=None):
+    """ntt_stockham_kernel (kernels/ntt_kernels.cu:213-243): one out-of-place stage over one polynomial."""
+    if inv0 is None:
+        inv0 = mont_inverse(q)
+    _chk(data, tw); out = data.copy(); Q = _one(q)
+    lib().orc_ref_stockham_stage(_p(out), _p(data), _p(tw), _p(Q), inv0, data.shape[0], stage); return out
 
 
 def ref_pointwise_kernel(a, b, q, inv0=None):

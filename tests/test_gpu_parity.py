@@ -984,3 +984,23 @@ def test_reference_literal_kernels_with_real_tables_are_the_cyclic_dft(eng, orac
     assert oracle.from_limbs(dX.download((n, 4))) == [sum(x[j] * pow(om, j * k, q) for j in range(n)) % q for k in range(n)]
     eng.ref_inverse_kernel_literal(dX, _up(eng, itw), q, inv0, n_inv_m, n)
     assert oracle.from_limbs(dX.download((n, 4))) in (xb, x)
+
+
+def test_reference_stockham_stage_matches_oracle(eng, oracle):
+    """ntt_stockham_kernel (kernels/ntt_kernels.cu:213-243): one out-of-place stage, every stage of n = 256, batch 3."""
+    rng = random.Random(2)
+    n, q, batch = 256, nm.ntt_primes(60, 4096, 1)[0], 3
+    tw = oracle.to_limbs([rng.randrange(q) for _ in range(n)])
+    x = oracle.to_limbs([rng.randrange(q) for _ in range(batch * n)])
+    inv0 = oracle.mont_inverse(q)
+    dT = _up(eng, tw); dA, dB = _up(eng, x), eng.DeviceBuffer(x.nbytes)
+    want = x
+    for stage in range(8):
+        eng.ref_stockham_stage_literal(dB, dA, dT, q, inv0, n, stage, batch)
+        want = np.concatenate([oracle.ref_stockham_stage(np.ascontiguousarray(want[b * n:(b + 1) * n]), tw, q, stage) for b in range(batch)])
+        assert np.array_equal(dB.download(x.shape), want)
+        dA, dB = dB, dA
+    with pytest.raises(eng.FheError):
+        eng.ref_stockham_stage_literal(dA, dA, dT, q, inv0, n, 0, batch)
+    with pytest.raises(eng.FheError):
+        eng.ref_stockham_stage_literal(dB, dA, dT, q, inv0, n, 8, batch)

@@ -487,3 +487,21 @@ def test_negacyclic_reduce_folds_the_upper_half(oracle):
         for j, y in enumerate(b):
             full[i + j] = (full[i + j] + x * y) % q
     assert oracle.from_limbs(oracle.negacyclic_reduce(oracle.to_limbs(full), q))[:n] == nm.negacyclic_mul_direct(a, b, q)
+
+
+def test_stockham_stages_equal_the_in_place_forward_kernel(oracle):
+    """ntt_stockham_kernel (kernels/ntt_kernels.cu:213-243) stage by stage is the same butterfly network as the in-place forward
+    kernel; only the table indexing differs: Stockham reads tw[j * n / 2m], the in-place kernel (with its log_n = log2(n) + 1)
+    reads tw[j * n / m], i.e. twice the index -- so the two agree when the in-place kernel is given the table spread out by 2."""
+    rng = random.Random(12)
+    for n, q in [(8, 12289), (64, 40961), (256, nm.ntt_primes(60, 4096, 1)[0])]:
+        t = [rng.randrange(q) for _ in range(n)]
+        tw = oracle.to_limbs(t)
+        spread = [0] * n
+        for k in range(n // 2):
+            spread[2 * k] = t[k]
+        x = oracle.to_limbs([rng.randrange(q) for _ in range(n)])
+        y = x
+        for stage in range(n.bit_length() - 1):
+            y = oracle.ref_stockham_stage(y, tw, q, stage)
+        assert np.array_equal(y, oracle.ref_forward_kernel(x, oracle.to_limbs(spread), q))
