@@ -82,6 +82,7 @@ def lib():
         "fhe_ref_forward_kernel_literal": ([vp, vp, U64x4, u64, u32, u32, vp], ci),
         "fhe_ref_inverse_kernel_literal": ([vp, vp, U64x4, u64, U64x4, u32, u32, vp], ci),
         "fhe_ref_stockham_stage_literal": ([vp, vp, vp, U64x4, u64, u32, u32, u32, vp], ci),
+        "fhe_bit_reverse": ([vp, u32, u32, vp], ci),
         "fhe_sample_uniform_lcg": ([vp, U64x4, u64, sz, vp], ci),
         "fhe_sample_gaussian_placeholder": ([vp, U64x4, u64, sz, vp], ci),
         "fhe_rns_sample_ternary": ([vp, vp, ctypes.c_double, u64, u32], ci),
@@ -212,6 +213,10 @@ def ref_inverse_kernel_literal(data, inv_twiddles, q, inv0, n_inv, n, batch=1, s
 
 def ref_stockham_stage_literal(output, data, twiddles, q, inv0, n, stage, batch=1, stream=None):
     _check(lib().fhe_ref_stockham_stage_literal(_ptr(output), _ptr(data), _ptr(twiddles), _q4(q), inv0, n, stage, batch, stream))
+
+
+def bit_reverse(data, n, batch=1, stream=None):
+    _check(lib().fhe_bit_reverse(_ptr(data), n, batch, stream))
 
 
 def sample_uniform_lcg(out, q, seed, count, stream=None):

@@ -214,6 +214,18 @@ extern "C" int fhe_ref_stockham_stage_literal(void *d_output, const void *d_inpu
     return post_launch((hipStream_t)stream, "ref_stockham_stage_kernel");
 }
 
+extern "C" int fhe_bit_reverse(void *d_data, uint32_t n, uint32_t batch, void *stream) {
+    if (!d_data) return fail(FHE_ERR_INVALID_ARG, "fhe_bit_reverse: null argument");
+    if (n < 2 || (n & (n - 1))) return fail(FHE_ERR_INVALID_ARG, "fhe_bit_reverse: n must be a power of two >= 2");
+    if (!batch) return fail(FHE_ERR_INVALID_ARG, "fhe_bit_reverse: batch must be >= 1");
+    int rc = ensure_device(); if (rc) return rc;
+    (void)hipGetLastError();
+    uint32_t log_n = 0; while ((1u << log_n) < n) log_n++;
+    const size_t count = (size_t)batch * n;
+    hipLaunchKernelGGL(fhe_dev::bit_reverse_kernel, dim3(ew_grid(count)), dim3(256), 0, (hipStream_t)stream, (fhe_dev::u256 *)d_data, log_n, count);
+    return post_launch((hipStream_t)stream, "bit_reverse_kernel");
+}
+
 // ------------------------------------------------------------------------------------------------------
 // engine handle
 // ------------------------------------------------------------------------------------------------------

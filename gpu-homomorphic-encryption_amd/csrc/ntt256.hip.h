@@ -371,6 +371,26 @@ ref_stockham_stage_kernel(u256 *__restrict__ output, const u256 *__restrict__ in
     }
 }
 
+// bit_reverse_kernel's intent (kernels/ntt_kernels.cu:140-161): in-place bit-reversal permutation of each polynomial, swapping
+// only where idx < rev(idx).  The reference reverses over popc(n-1)+1 = log2(n)+1 bits, which sends half of the indices past
+// the array (undefined); this kernel reverses over log2(n) bits.  It converts between natural order and the order
+// fhe_ntt_forward leaves its values in (X[k] sits at position bitrev(k)).
+__global__ void __launch_bounds__(256)
+bit_reverse_kernel(u256 *__restrict__ data, uint32_t log_n, size_t count /* batch * n */) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const uint32_t n = 1u << log_n;
+    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < count; g += stride) {
+        const uint32_t idx = (uint32_t)(g & (n - 1));
+        const uint32_t rev = __brev(idx) >> (32 - log_n);
+        if (idx < rev) {
+            u256 *d = data + (g - idx);
+            const u256 a = load_u256(d + idx), b = load_u256(d + rev);
+            store_u256(d + idx, b);
+            store_u256(d + rev, a);
+        }
+    }
+}
+
 // (X^shift[b] - 1) * p on full-width containers (see monomial_mul_sub_kernel in ntt_lds.hip.h)
 __global__ void __launch_bounds__(256)
 monomial_mul_sub256_kernel(u256 *__restrict__ out, const u256 *__restrict__ in, const uint32_t *__restrict__ shifts,

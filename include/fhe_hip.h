@@ -116,6 +116,11 @@ int fhe_ref_inverse_kernel_literal(void *d_data, const void *d_inv_twiddles, con
 int fhe_ref_stockham_stage_literal(void *d_output, const void *d_input, const void *d_twiddles, const uint64_t q[4], uint64_t inv0, uint32_t n,
                                    uint32_t stage, uint32_t batch, void *stream);
 
+/* bit_reverse_kernel's intent (kernels/ntt_kernels.cu:140-161): in-place bit-reversal permutation of every polynomial of a
+ * [batch][n] buffer over log2(n) bits (the reference's popc(n-1)+1 bits index out of bounds).  The engine's transforms need no
+ * such pass (DIF/DIT pairing); this entry converts between natural order and the order fhe_ntt_forward leaves its values in. */
+int fhe_bit_reverse(void *d_data, uint32_t n, uint32_t batch, void *stream);
+
 /* ---- single-modulus engine: fhe::NTTEngine -------------------------------------------------- */
 /* NTTEngine::NTTEngine(n, modulus) (src/ntt.cu:7-22) + precompute_twiddle_factors (:77-107), with the
  * root / inverse / table placeholders replaced by real values.  q prime, q = 1 (mod 2n), q < 2^255,

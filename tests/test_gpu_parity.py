@@ -1004,3 +1004,26 @@ def test_reference_stockham_stage_matches_oracle(eng, oracle):
         eng.ref_stockham_stage_literal(dA, dA, dT, q, inv0, n, 0, batch)
     with pytest.raises(eng.FheError):
         eng.ref_stockham_stage_literal(dB, dA, dT, q, inv0, n, 8, batch)
+
+
+def test_bit_reverse_permutation_and_natural_order_transform(eng, oracle):
+    """bit_reverse_kernel's intent (kernels/ntt_kernels.cu:140-161) over log2(n) bits; after it the forward transform's values
+    are in natural order: X[k] = sum_j x[j] psi^((2k+1) j)."""
+    rng = random.Random(6)
+    for n, batch in [(2, 1), (8, 3), (1024, 2), (65536, 1)]:
+        x = oracle.to_limbs([rng.getrandbits(200) for _ in range(batch * n)])
+        d = _up(eng, x)
+        eng.bit_reverse(d, n, batch)
+        got = d.download(x.shape).reshape(batch, n, 4)
+        bits = n.bit_length() - 1
+        perm = np.array([nm.bitrev(i, bits) for i in range(n)])
+        assert np.array_equal(got, x.reshape(batch, n, 4)[:, perm])
+        eng.bit_reverse(d, n, batch)
+        assert np.array_equal(d.download(x.shape), x)                      # an involution
+    n, q = 64, 12289
+    e = eng.NttEngine(n, q)
+    xs = [rng.randrange(q) for _ in range(n)]
+    d = _up(eng, oracle.to_limbs(xs))
+    e.forward(d); eng.bit_reverse(d, n); eng.capi.sync()
+    psi = nm.find_psi(n, q)
+    assert oracle.from_limbs(d.download((n, 4))) == [sum(xs[j] * pow(psi, (2 * k + 1) * j, q) for j in range(n)) % q for k in range(n)]
