@@ -79,6 +79,8 @@ def lib():
         "fhe_blind_rotate_step": ([vp, vp, vp, vp, vp, vp, vp, vp, u32], ci),
         "fhe_blind_rotate": ([vp, P(vp), P(vp), u32, vp, vp, vp, vp, vp, u32], ci),
         "fhe_rns_fast_base_convert": ([vp, vp, vp, vp, u32], ci),
+        "fhe_rns_base_create": ([P(vp), vp, u32], ci),
+        "fhe_rns_mul_mont_literal": ([vp, vp, vp, vp, u32], ci),
         "fhe_ref_forward_kernel_literal": ([vp, vp, U64x4, u64, u32, u32, vp], ci),
         "fhe_ref_inverse_kernel_literal": ([vp, vp, U64x4, u64, U64x4, u32, u32, vp], ci),
         "fhe_ref_stockham_stage_literal": ([vp, vp, vp, U64x4, u64, u32, u32, u32, vp], ci),
@@ -305,7 +307,10 @@ class RnsNttEngine:
         L = len(moduli)
         arr = (U64x4 * L)(*[_q4(q) for q in moduli])
         h = ctypes.c_void_p()
-        _check(lib().fhe_rns_ntt_create(ctypes.byref(h), n, ctypes.cast(arr, ctypes.c_void_p), L))
+        if n is None:                      # RNS base without a ring (RNSContext): degree-1 engine, buffers [count][L]
+            _check(lib().fhe_rns_base_create(ctypes.byref(h), ctypes.cast(arr, ctypes.c_void_p), L)); n = 1
+        else:
+            _check(lib().fhe_rns_ntt_create(ctypes.byref(h), n, ctypes.cast(arr, ctypes.c_void_p), L))
         self.h, self.n, self.L, self.moduli = h, n, L, list(moduli)
 
     @property
@@ -329,6 +334,9 @@ class RnsNttEngine:
 
     def poly_add(self, d_r, d_a, d_b, batch=1):
         _check(lib().fhe_rns_poly_add(self.h, _ptr(d_r), _ptr(d_a), _ptr(d_b), batch))
+
+    def mul_mont_literal(self, d_r, d_a, d_b, batch=1):
+        _check(lib().fhe_rns_mul_mont_literal(self.h, _ptr(d_r), _ptr(d_a), _ptr(d_b), batch))
 
     def poly_sub(self, d_r, d_a, d_b, batch=1):
         _check(lib().fhe_rns_poly_sub(self.h, _ptr(d_r), _ptr(d_a), _ptr(d_b), batch))

@@ -382,16 +382,29 @@ static int build_limbs256(fhe_rns_ntt *h, const std::vector<fhe_host::NttConstan
     return upload(h, limbs, &h->d_limbs);
 }
 
-static int create_impl(fhe_rns_ntt **out, uint32_t n, const uint64_t (*moduli)[4], uint32_t L) {
+// base_only: an RNS base without a ring (RNSContext, include/rns.cuh:27-66): the handle is an engine of degree n = 1, whose
+// buffers [batch][L][1] are exactly RNSContext's interleaved [count][num_primes] layout (src/rns.cu:103-104) and whose
+// transforms are the identity (Z_q[x]/(x + 1) = Z_q), so every container-level entry point works on it unchanged.
+static fhe_host::BuildStatus base_constants(const U256 &q, fhe_host::NttConstants &out) {
+    if (!(q.w[0] & 1) || (q.w[3] >> 63) || q.bit_length() < 2 || !fhe_host::is_prime(q)) return fhe_host::BUILD_BAD_MODULUS;
+    out.n = 1; out.log_n = 0; out.q = q;
+    fhe_host::sub_to(out.psi, q, U256(1)); out.psi_inv = out.psi;     // the primitive 2nd root of unity, -1
+    out.n_inv = U256(1);
+    out.tw.assign(1, U256(1)); out.itw.assign(1, U256(1));
+    return fhe_host::BUILD_OK;
+}
+static int create_impl(fhe_rns_ntt **out, uint32_t n, const uint64_t (*moduli)[4], uint32_t L, bool base_only = false) {
     if (!out || !moduli) return fail(FHE_ERR_INVALID_ARG, "null argument");
     *out = nullptr;
-    if (n < 8 || n > 65536 || (n & (n - 1))) return fail(FHE_ERR_INVALID_ARG, "polynomial degree must be a power of two in [8, 65536]");
+    if (base_only) n = 1;
+    else if (n < 8 || n > 65536 || (n & (n - 1))) return fail(FHE_ERR_INVALID_ARG, "polynomial degree must be a power of two in [8, 65536]");
     if (L < 1 || L > 64) return fail(FHE_ERR_INVALID_ARG, "num_primes must be in [1, 64]");
     std::vector<fhe_host::NttConstants> cs(L);
     int max_bits = 0;
     for (uint32_t l = 0; l < L; l++) {
         U256 q = U256::from(moduli[l]);
-        fhe_host::BuildStatus st = fhe_host::build_constants(n, q, cs[l]);
+        for (uint32_t k = 0; k < l; k++) if (q == cs[k].q) return fail(FHE_ERR_BAD_MODULUS, "the RNS primes must be pairwise distinct");
+        fhe_host::BuildStatus st = base_only ? base_constants(q, cs[l]) : fhe_host::build_constants(n, q, cs[l]);
         if (st != fhe_host::BUILD_OK) {
             char buf[160];
             snprintf(buf, sizeof buf, "modulus %u (low limb 0x%llx) rejected: need an odd prime < 2^255 with q = 1 (mod 2n)", l,
@@ -571,6 +584,9 @@ static int do_ct_multiply(fhe_rns_ntt *h, void *c0, void *c1, void *c2, const vo
 extern "C" int fhe_rns_ntt_create(fhe_rns_ntt_t **out, uint32_t n, const uint64_t (*moduli)[4], uint32_t num_primes) {
     return create_impl(out, n, moduli, num_primes);
 }
+extern "C" int fhe_rns_base_create(fhe_rns_ntt_t **out, const uint64_t (*primes)[4], uint32_t num_primes) {
+    return create_impl(out, 1, primes, num_primes, true);
+}
 extern "C" int fhe_rns_ntt_destroy(fhe_rns_ntt_t *h) { destroy_impl(h); return FHE_OK; }
 extern "C" int fhe_rns_ntt_set_stream(fhe_rns_ntt_t *h, void *stream) {
     if (!h) return fail(FHE_ERR_INVALID_ARG, "null handle");
@@ -602,6 +618,13 @@ extern "C" int fhe_rns_poly_add(fhe_rns_ntt_t *h, void *r, const void *a, const 
     int rc = check_call(h, batch, "poly_add"); if (rc) return rc;
     if (!r || !a || !b) return fail(FHE_ERR_INVALID_ARG, "poly_add: null argument");
     return do_ew<1>(h, r, a, b, batch, "poly_add");
+}
+extern "C" int fhe_rns_mul_mont_literal(fhe_rns_ntt_t *h, void *r, const void *a, const void *b, uint32_t batch) {
+    int rc = check_call(h, batch, "mul_mont_literal"); if (rc) return rc;
+    if (!r || !a || !b) return fail(FHE_ERR_INVALID_ARG, "mul_mont_literal: null argument");
+    if (h->width != FHE_WIDTH_256) return fail(FHE_ERR_UNSUPPORTED, "mul_mont_literal: R = 2^256 Montgomery products exist on full-width handles only "
+                                                                    "(an RNS base from fhe_rns_base_create, or FHE_HIP_FORCE_WIDTH=256)");
+    return run256_ew<3>(h, r, a, b, batch * h->L, "mul_mont_literal");
 }
 extern "C" int fhe_rns_poly_sub(fhe_rns_ntt_t *h, void *r, const void *a, const void *b, uint32_t batch) {
     int rc = check_call(h, batch, "poly_sub"); if (rc) return rc;

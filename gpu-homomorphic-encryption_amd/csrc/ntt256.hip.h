@@ -96,7 +96,7 @@ ntt256_inv_pass(u256 *__restrict__ data, const Limb256 *__restrict__ limbs, uint
 }
 
 // Element-wise over [batch][L][n] with per-limb moduli.  OP 0: plain product a*b mod q
-// (= mont(mont(a,b), R^2)); 1: add_mod; 2: sub_mod.
+// (= mont(mont(a,b), R^2)); 1: add_mod; 2: sub_mod; 3: literal mul_mod_montgomery(a, b) (rns_mul_kernel).
 template <int OP>
 __global__ void __launch_bounds__(256)
 ew256_rns_kernel(u256 *__restrict__ r, const u256 *__restrict__ a, const u256 *__restrict__ b,
@@ -107,7 +107,8 @@ ew256_rns_kernel(u256 *__restrict__ r, const u256 *__restrict__ a, const u256 *_
         u256 x = load_u256(a + g), y = load_u256(b + g), o;
         if (OP == 0) o = mont_mul_fips(mont_mul_fips(x, y, P.q, (uint32_t)P.inv0), P.r2, P.q, (uint32_t)P.inv0);
         else if (OP == 1) o = add_mod(x, y, P.q);
-        else o = sub_mod(x, y, P.q);
+        else if (OP == 2) o = sub_mod(x, y, P.q);
+        else o = mont_mul(x, y, P.q, P.inv0);          // 3: rns_mul_kernel, literal (src/rns.cu:160-181): carries R^-1
         store_u256(r + g, o);
     }
 }

@@ -144,6 +144,12 @@ int fhe_ntt_multiply(fhe_ntt_t *h, void *d_r, const void *d_a, const void *d_b, 
 /* ---- RNS engine: fhe::RNS_NTTEngine ---------------------------------------------------------- */
 /* RNS_NTTEngine::RNS_NTTEngine(n, rns_moduli, num_primes) (src/ntt.cu:122-145): moduli are copied. */
 int fhe_rns_ntt_create(fhe_rns_ntt_t **out, uint32_t n, const uint64_t (*moduli)[4], uint32_t num_primes);
+/* RNSContext::RNSContext(primes) (include/rns.cuh:27-66, src/rns.cu:6-29): an RNS base WITHOUT a ring.  The handle is an engine of
+ * degree n = 1: its buffers [batch][L][1] are exactly RNSContext's interleaved [count][num_primes] layout (src/rns.cu:103-104),
+ * `batch` is the reference's `count`, and every container-level entry point (fhe_rns_to_rns, fhe_rns_from_rns, fhe_rns_poly_add /
+ * sub, fhe_rns_ntt_pointwise, fhe_rns_mul_mont_literal, fhe_rns_rescale_drop_last, fhe_rns_fast_base_convert, the samplers) works on
+ * it.  Primes: pairwise distinct odd primes < 2^255 (no congruence condition). */
+int fhe_rns_base_create(fhe_rns_ntt_t **out, const uint64_t (*primes)[4], uint32_t num_primes);
 int fhe_rns_ntt_destroy(fhe_rns_ntt_t *h);                                    /* src/ntt.cu:147-156 */
 int fhe_rns_ntt_set_stream(fhe_rns_ntt_t *h, void *stream);
 int fhe_rns_ntt_width_class(const fhe_rns_ntt_t *h);
@@ -156,6 +162,9 @@ int fhe_rns_ntt_multiply(fhe_rns_ntt_t *h, void *d_r, const void *d_a, const voi
 /* PolynomialOps::add / sub over RNS polynomials (src/polynomial.cu:36-52), per-limb moduli. */
 int fhe_rns_poly_add(fhe_rns_ntt_t *h, void *d_r, const void *d_a, const void *d_b, uint32_t batch);
 int fhe_rns_poly_sub(fhe_rns_ntt_t *h, void *d_r, const void *d_a, const void *d_b, uint32_t batch);
+/* rns_mul_kernel / RNSContext::mul_rns (src/rns.cu:84-91, :160-181), LITERAL: r = mul_mod_montgomery(a, b, q_l, inv_l) per limb, i.e. the
+ * product carries R^-1 = 2^-256 exactly as in the reference (fhe_rns_ntt_pointwise is the plain product).  Full-width handles only. */
+int fhe_rns_mul_mont_literal(fhe_rns_ntt_t *h, void *d_r, const void *d_a, const void *d_b, uint32_t batch);
 /* FHEContext::multiply tensor product (src/fhe.cu:199-218), relinearisation excluded (:220 is a stub):
  * c0 = a0*b0, c1 = a0*b1 + a1*b0, c2 = a1*b1.  4 forward + 3 inverse transforms instead of the
  * reference's 8 + 4 (results identical: modular arithmetic is exact). */

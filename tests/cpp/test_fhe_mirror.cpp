@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "fhe/fhe.hpp"
+#include "fhe/rns.hpp"
 
 using namespace fhe;
 typedef unsigned __int128 u128;
@@ -328,6 +329,80 @@ static void test_fhe_operations_device_sampling() {
     delete pk.pk0; delete pk.pk1; delete sk.sk; delete pa.poly; delete pb.poly; delete pr.poly;
 }
 
+// fhe::RNSContext (include/rns.cuh:27-66): interleaved [count][num_primes] buffers, literal add / mul kernels, real conversions.
+static void test_rns_context() {
+    std::cout << "Testing RNSContext..." << std::endl;
+    const std::vector<uint64_t> ps = {12289, 40961, 1073479681ull, 1152921504606584833ull};      // any distinct odd primes: no NTT condition
+    std::vector<uint256_t> primes(ps.begin(), ps.end());
+    RNSContext rns(primes);
+    REQUIRE(rns.num_primes() == 4 && rns.base().primes[1] == uint256_t(40961));
+    const uint32_t count = 1000, L = 4;
+    std::mt19937_64 rng(5);
+    unsigned __int128 Q = 1; for (uint64_t p : ps) Q *= p;                                       // ~2^119
+    std::vector<unsigned __int128> va(count), vb(count);
+    std::vector<uint256_t> ha(count), hb(count);
+    for (uint32_t i = 0; i < count; i++) {
+        va[i] = (((unsigned __int128)rng() << 64) | rng()) % Q; vb[i] = (((unsigned __int128)rng() << 64) | rng()) % Q;
+        ha[i] = uint256_t((uint64_t)va[i], (uint64_t)(va[i] >> 64), 0, 0); hb[i] = uint256_t((uint64_t)vb[i], (uint64_t)(vb[i] >> 64), 0, 0);
+    }
+    uint256_t *dA = device_alloc(count), *dB = device_alloc(count), *dRA = device_alloc((size_t)count * L), *dRB = device_alloc((size_t)count * L),
+              *dR = device_alloc((size_t)count * L), *dV = device_alloc(count);
+    copy_to_device(dA, ha.data(), count); copy_to_device(dB, hb.data(), count);
+    rns.to_rns(dRA, dA, count); rns.to_rns(dRB, dB, count);
+    std::vector<uint256_t> r((size_t)count * L);
+    device_synchronize(); copy_to_host(r.data(), dRA, r.size());
+    for (uint32_t i = 0; i < count; i++) for (uint32_t l = 0; l < L; l++) REQUIRE(r[(size_t)i * L + l] == uint256_t((uint64_t)(va[i] % ps[l])));   // interleaved layout
+    rns.from_rns(dV, dRA, count);
+    std::vector<uint256_t> back(count); device_synchronize(); copy_to_host(back.data(), dV, count);
+    for (uint32_t i = 0; i < count; i++) REQUIRE(back[i] == ha[i]);
+    // add / sub / plain product commute with the CRT; mul_rns is the literal Montgomery product (carries 2^-256 per limb)
+    rns.add_rns(dR, dRA, dRB, count); rns.from_rns(dV, dR, count); device_synchronize(); copy_to_host(back.data(), dV, count);
+    for (uint32_t i = 0; i < count; i++) { unsigned __int128 w = (va[i] + vb[i]) % Q; REQUIRE(back[i] == uint256_t((uint64_t)w, (uint64_t)(w >> 64), 0, 0)); }
+    rns.sub_rns(dR, dRA, dRB, count); rns.from_rns(dV, dR, count); device_synchronize(); copy_to_host(back.data(), dV, count);
+    for (uint32_t i = 0; i < count; i++) { unsigned __int128 w = (va[i] + Q - vb[i]) % Q; REQUIRE(back[i] == uint256_t((uint64_t)w, (uint64_t)(w >> 64), 0, 0)); }
+    rns.mul_rns_plain(dR, dRA, dRB, count); device_synchronize(); copy_to_host(r.data(), dR, r.size());
+    for (uint32_t i = 0; i < count; i++) for (uint32_t l = 0; l < L; l++)
+        REQUIRE(r[(size_t)i * L + l] == uint256_t((uint64_t)((unsigned __int128)(uint64_t)(va[i] % ps[l]) * (uint64_t)(vb[i] % ps[l]) % ps[l])));
+    rns.mul_rns(dR, dRA, dRB, count); device_synchronize(); copy_to_host(r.data(), dR, r.size());
+    auto pow_mod = [](unsigned __int128 b, unsigned e, uint64_t m) { unsigned __int128 a = 1; b %= m; for (; e; e >>= 1) { if (e & 1) a = a * b % m; b = b * b % m; } return (uint64_t)a; };
+    for (uint32_t l = 0; l < L; l++) {
+        const uint64_t q = ps[l];
+        unsigned __int128 base = pow_mod(2, 256, q), acc = 1; uint64_t e = q - 2;      // acc = 2^-256 mod q = (2^256)^(q-2)
+        for (; e; e >>= 1) { if (e & 1) acc = acc * base % q; base = base * base % q; }
+        for (uint32_t i = 0; i < count; i += 97) {
+            const unsigned __int128 want = (unsigned __int128)(uint64_t)(va[i] % q) * (uint64_t)(vb[i] % q) % q * acc % q;
+            REQUIRE(r[(size_t)i * L + l] == uint256_t((uint64_t)want));
+        }
+    }
+    // mod_switch_rns: two levels down = round(round(x / q3) / q2) in the base {q0, q1}
+    uint256_t *dS = device_alloc((size_t)count * 2);
+    rns.mod_switch_rns(dS, dRA, 0, 2, count);
+    std::vector<uint256_t> s2((size_t)count * 2); device_synchronize(); copy_to_host(s2.data(), dS, s2.size());
+    for (uint32_t i = 0; i < count; i += 13) {
+        unsigned __int128 x = va[i];
+        // centred rounding as fhe_rns_rescale_drop_last defines it: (x - [x]_q) / q with [x]_q the centred residue
+        for (int drop = 3; drop >= 2; drop--) {
+            const uint64_t q = ps[drop]; uint64_t c = (uint64_t)(x % q);
+            if (c > q / 2) x = (x + (q - c)) / q; else x = (x - c) / q;
+        }
+        REQUIRE(s2[(size_t)i * 2] == uint256_t((uint64_t)(x % ps[0])) && s2[(size_t)i * 2 + 1] == uint256_t((uint64_t)(x % ps[1])));
+    }
+    // base_extend into a disjoint base: x + alpha * Q with 0 <= alpha < L
+    RNSContext target(std::vector<uint256_t>{uint256_t(65537), uint256_t(786433)});
+    uint256_t *dE = device_alloc((size_t)count * 2);
+    rns.base_extend(dE, dRA, target, count);
+    std::vector<uint256_t> ext((size_t)count * 2); device_synchronize(); copy_to_host(ext.data(), dE, ext.size());
+    for (uint32_t i = 0; i < count; i += 7) {
+        bool ok = false;
+        for (unsigned alpha = 0; alpha < L && !ok; alpha++)
+            ok = ext[(size_t)i * 2] == uint256_t((uint64_t)((va[i] % 65537 + (unsigned __int128)alpha * (Q % 65537)) % 65537)) &&
+                 ext[(size_t)i * 2 + 1] == uint256_t((uint64_t)((va[i] % 786433 + (unsigned __int128)alpha * (Q % 786433)) % 786433));
+        REQUIRE(ok);
+    }
+    for (uint256_t *p : {dA, dB, dRA, dRB, dR, dV, dS, dE}) device_free(p);
+    std::cout << "  to_rns / from_rns / add / sub / mul (literal + plain) / mod_switch_rns / base_extend ok" << std::endl;
+}
+
 // tests/test_fhe.cu:275-318 shape (N = 8192), timing the multiply path instead of encrypt
 static void benchmark_multiply() {
     std::cout << "Benchmark: ciphertext tensor product, N = 8192, log_q = 120" << std::endl;
@@ -360,6 +435,7 @@ int main(int argc, char **argv) {
     test_fhe_multiply_relinearize();
     test_fhe_operations();
     test_fhe_operations_device_sampling();
+    test_rns_context();
     benchmark_multiply();
     std::cout << "ALL PASSED" << std::endl;
     return 0;

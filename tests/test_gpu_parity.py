@@ -1027,3 +1027,42 @@ def test_bit_reverse_permutation_and_natural_order_transform(eng, oracle):
     e.forward(d); eng.bit_reverse(d, n); eng.capi.sync()
     psi = nm.find_psi(n, q)
     assert oracle.from_limbs(d.download((n, 4))) == [sum(xs[j] * pow(psi, (2 * k + 1) * j, q) for j in range(n)) % q for k in range(n)]
+
+
+def test_rns_base_without_a_ring(eng, oracle):
+    """fhe_rns_base_create (RNSContext, include/rns.cuh:27-66): interleaved [count][num_primes] buffers, arbitrary distinct odd
+    primes; rns_add_kernel / rns_mul_kernel literal (src/rns.cu:143-181), conversions exact -- checked against Python integers."""
+    primes = [12289, 40961, (1 << 61) - 1, (1 << 127) - 1]                 # no NTT condition; a 127-bit Mersenne prime among them
+    e = eng.RnsNttEngine(None, primes)
+    assert e.n == 1 and e.width_class == eng.WIDTH_256
+    rng = random.Random(10)
+    count, L = 777, len(primes)
+    Q = 1
+    for p in primes:
+        Q *= p
+    va = [rng.randrange(Q) for _ in range(count)]; vb = [rng.randrange(Q) for _ in range(count)]
+    dA, dB = _up(eng, oracle.to_limbs(va)), _up(eng, oracle.to_limbs(vb))
+    dRA, dRB, dR = (eng.DeviceBuffer(count * L * 32) for _ in range(3))
+    e.to_rns(dRA, dA, count); e.to_rns(dRB, dB, count)
+    ra = oracle.from_limbs(dRA.download((count, L, 4)))
+    assert ra == [v % p for v in va for p in primes]                       # value-major, prime-minor: the reference's layout
+    dV = eng.DeviceBuffer(count * 32)
+    e.from_rns(dV, dRA, count)
+    assert oracle.from_limbs(dV.download((count, 4))) == va
+    e.poly_add(dR, dRA, dRB, count)
+    assert oracle.from_limbs(dR.download((count, L, 4))) == [(x + y) % p for x, y in zip(va, vb) for p in primes]
+    e.poly_sub(dR, dRA, dRB, count)
+    assert oracle.from_limbs(dR.download((count, L, 4))) == [(x - y) % p for x, y in zip(va, vb) for p in primes]
+    e.pointwise(dR, dRA, dRB, count)
+    assert oracle.from_limbs(dR.download((count, L, 4))) == [(x % p) * (y % p) % p for x, y in zip(va, vb) for p in primes]
+    e.mul_mont_literal(dR, dRA, dRB, count)                                # mul_mod_montgomery: carries 2^-256
+    assert oracle.from_limbs(dR.download((count, L, 4))) == [nm.mont_mul_ref(x % p, y % p, p) for x, y in zip(va, vb) for p in primes]
+    e.multiply(dR, dRA, dRB, count)                                        # the ring Z_q[x]/(x + 1) is Z_q: transforms are the identity
+    assert oracle.from_limbs(dR.download((count, L, 4))) == [(x % p) * (y % p) % p for x, y in zip(va, vb) for p in primes]
+    with pytest.raises(eng.FheError):
+        eng.RnsNttEngine(None, [12289, 12289])                             # not pairwise distinct
+    with pytest.raises(eng.FheError):
+        eng.RnsNttEngine(None, [12289, 40963])                             # 40963 = 13 * 23 * 137
+    narrow = eng.RnsNttEngine(8192, eng.find_ntt_primes(30, 8192, 2))
+    with pytest.raises(eng.FheError):
+        narrow.mul_mont_literal(dR, dRA, dRB, 1)                           # R = 2^256 products only exist on full-width handles
