@@ -48,8 +48,15 @@ public:
         check(fhe_u256_mont_mul_scalar(result.coeffs, a.coeffs, scalar.limbs, modulus_.limbs, mont_params_.inv.limbs[0], a.count(), nullptr),
               "PolynomialOps::mul_scalar");
     }
-    // mul_negacyclic (include/polynomial.cuh:38-39, undefined in the reference) is what mul_ntt computes here.
+    // mul / mul_negacyclic (include/polynomial.cuh:29,38-39, undefined in the reference) are what mul_ntt computes here:
+    // the product in Z_q[x]/(x^n + 1).
+    void mul(Polynomial &result, const Polynomial &a, const Polynomial &b) { mul_ntt(result, a, b); }
     void mul_negacyclic(Polynomial &result, const Polynomial &a, const Polynomial &b) { mul_ntt(result, a, b); }
+    // mod_switch (include/polynomial.cuh:41-42, undefined; its kernel poly_mod_switch_kernel is what FHEContext::decrypt
+    // launches, src/fhe.cu:181-184): result[i] = round(a[i] * new_modulus / modulus) mod new_modulus, new_modulus < 2^64.
+    void mod_switch(Polynomial &result, const Polynomial &a, const uint256_t &new_modulus) {
+        check(fhe_poly_mod_switch(result.coeffs, a.coeffs, modulus_.limbs, new_modulus.limbs, a.count(), nullptr), "PolynomialOps::mod_switch");
+    }
 
 private:
     uint32_t max_degree_;

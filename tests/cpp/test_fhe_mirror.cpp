@@ -115,7 +115,11 @@ static void test_polynomial_multiplication() {
         REQUIRE(sum[i] == uint256_t((a[i] + b[i]) % 40961));
         REQUIRE(a_after[i] == uint256_t(a[i]));                                    // operands preserved (src/ntt.cu:50-58)
     }
-    std::cout << "  product matches schoolbook, operands preserved" << std::endl;
+    ops.mul(ps, pa, pb); device_synchronize(); copy_to_host(sum.data(), ps.coeffs, N);        // mul == mul_ntt == mul_negacyclic
+    for (uint32_t i = 0; i < N; i++) REQUIRE(sum[i] == got[i]);
+    ops.mod_switch(ps, pa, uint256_t(257)); device_synchronize(); copy_to_host(sum.data(), ps.coeffs, N);
+    for (uint32_t i = 0; i < N; i++) REQUIRE(sum[i] == uint256_t(((a[i] * 257 + 40961 / 2) / 40961) % 257));   // round(a * t / q) mod t
+    std::cout << "  product matches schoolbook, operands preserved; mod_switch rounds" << std::endl;
 }
 
 // tests/test_fhe.cu:169-273, multiply path only: the tensor product of two 2-component ciphertexts
