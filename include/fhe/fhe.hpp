@@ -90,6 +90,25 @@ public:
         result.noise_budget = std::min(a.noise_budget, b.noise_budget);
         result.level = std::max(a.level, b.level);
     }
+    // sub / add_plain / sub_plain / multiply_plain (include/fhe.cuh:98-104, declared only in the reference).  Plaintexts are the
+    // encode()d polynomials (reduced mod t in every limb); with the mirror's BGV-style encryption c0 + c1*s = m + t*e they act
+    // on the message directly: component-wise subtraction, +-pt on c0, every component times pt.
+    void sub(Ciphertext &result, const Ciphertext &a, const Ciphertext &b) {
+        if (a.components.size() != b.components.size()) throw std::runtime_error("FHEContext::sub: ciphertexts of different size");
+        ensure_components(result, a.components.size());
+        for (size_t i = 0; i < a.components.size(); i++)
+            params_.rns_ntt->sub_rns(result.components[i]->coeffs, a.components[i]->coeffs, b.components[i]->coeffs);
+        result.noise_budget = std::min(a.noise_budget, b.noise_budget);
+        result.level = std::max(a.level, b.level);
+    }
+    void add_plain(Ciphertext &result, const Ciphertext &ct, const Plaintext &pt) { plain_addsub(result, ct, pt, true); }
+    void sub_plain(Ciphertext &result, const Ciphertext &ct, const Plaintext &pt) { plain_addsub(result, ct, pt, false); }
+    void multiply_plain(Ciphertext &result, const Ciphertext &ct, const Plaintext &pt) {
+        ensure_components(result, ct.components.size());
+        for (size_t i = 0; i < ct.components.size(); i++)
+            params_.rns_ntt->multiply_rns(result.components[i]->coeffs, ct.components[i]->coeffs, pt.poly->coeffs);
+        result.noise_budget = ct.noise_budget; result.level = ct.level;
+    }
 
     // src/fhe.cu:199-224: tensor product in ONE fused launch (4 forward + 3 inverse transforms instead of
     // the reference's 8 + 4), then relinearize().
@@ -285,6 +304,17 @@ private:
     SchemeParams params_;
     std::mt19937_64 rng_{0x5EED0000ull};
     bool device_sampling_ = false;
+
+    void plain_addsub(Ciphertext &result, const Ciphertext &ct, const Plaintext &pt, bool add_it) {
+        ensure_components(result, ct.components.size());
+        RNS_NTTEngine &E = *params_.rns_ntt;
+        if (add_it) E.add_rns(result.components[0]->coeffs, ct.components[0]->coeffs, pt.poly->coeffs);
+        else E.sub_rns(result.components[0]->coeffs, ct.components[0]->coeffs, pt.poly->coeffs);
+        for (size_t i = 1; i < ct.components.size(); i++)
+            if (result.components[i] != ct.components[i])
+                check(fhe_hip_memcpy_d2d(result.components[i]->coeffs, ct.components[i]->coeffs, ct.components[i]->count() * sizeof(uint256_t)), "plain op copy");
+        result.noise_budget = ct.noise_budget; result.level = ct.level;
+    }
 
     // ---- where keygen / encrypt get their random polynomials: host generator (default) or the device samplers --------------
     void draw_ternary(Polynomial &p) { if (device_sampling_) sample_ternary_polynomial(p); else upload_signed(p, sample_small(1)); }

@@ -272,6 +272,23 @@ static void test_fhe_operations() {
     std::cout << "  Multiplication result: " << out[0] << " " << out[1] << " " << out[2] << " " << out[3] << " (expected: 15 60 135 240)" << std::endl;
     REQUIRE(out[0] == 15 && out[1] == 60 && out[2] == 135 && out[3] == 240);
     for (size_t i = 4; i < out.size(); i++) REQUIRE(out[i] == 0);
+    // sub / add_plain / sub_plain / multiply_plain (declared only in the reference, include/fhe.cuh:98-104)
+    {
+        Ciphertext cd, cp;
+        ctx.sub(cd, cb, ca);                                                // slots wrap mod t: 3 - 5 = t - 2
+        ctx.decrypt(pr, cd, sk); ctx.decode(out, pr);
+        const uint64_t t = ctx.params().t;
+        REQUIRE(out[0] == t - 2 && out[1] == t - 4 && out[2] == t - 6 && out[3] == t - 8 && out[4] == 0);
+        ctx.add_plain(cp, ca, pb);
+        ctx.decrypt(pr, cp, sk); ctx.decode(out, pr);
+        REQUIRE(out[0] == 8 && out[1] == 16 && out[2] == 24 && out[3] == 32);
+        ctx.sub_plain(cp, ca, pb);
+        ctx.decrypt(pr, cp, sk); ctx.decode(out, pr);
+        REQUIRE(out[0] == 2 && out[1] == 4 && out[2] == 6 && out[3] == 8);
+        ctx.multiply_plain(cp, ca, pb);
+        ctx.decrypt(pr, cp, sk); ctx.decode(out, pr);
+        REQUIRE(out[0] == 15 && out[1] == 60 && out[2] == 135 && out[3] == 240 && out[4] == 0);
+    }
     // depth 2: (a*b)*a = 75 600 2025 4800
     Ciphertext c3;
     ctx.multiply(c3, cprod, ca, rlk);
