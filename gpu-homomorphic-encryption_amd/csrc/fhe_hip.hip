@@ -804,6 +804,8 @@ extern "C" int fhe_ct_relinearize(fhe_rns_ntt_t *h, const fhe_relin_keys_t *rk, 
         fhe_dev::LdsArgs A{fhe_dev::LDS_KEYSWITCH, d_c0, d_c1, nullptr, d_c2, nullptr, nullptr, nullptr, h->d_limbs, h->L, batch * h->L, h->stream};
         A.kb = rk->d_pkb; A.ka = rk->d_pka; A.K = rk->K; A.w = rk->decomp_bits;
         A.global_twiddles = getenv("FHE_HIP_NO_LDS_TWIDDLES") != nullptr;
+    A.single_transforms = getenv("FHE_HIP_NO_PAIRED_TRANSFORMS") != nullptr;
+    A.paired_everywhere = getenv("FHE_HIP_PAIRED_TRANSFORMS") != nullptr;
         fn(A);
         return post_launch(h->stream, "ntt_keyswitch_kernel");
     }
@@ -985,6 +987,8 @@ static int blind_rotate_step_fused(fhe_rns_ntt_t *h, const fhe_relin_keys_t *r0,
     fhe_dev::LdsArgs A{fhe_dev::LDS_EXTPROD, out0, out1, nullptr, in0, in1, nullptr, nullptr, h->d_limbs, h->L, batch * h->L, h->stream};
     A.kb = r0->d_pkb; A.ka = r0->d_pka; A.kb1 = r1->d_pkb; A.ka1 = r1->d_pka; A.K = r0->K; A.w = r0->decomp_bits; A.shifts = d_shifts;
     A.global_twiddles = getenv("FHE_HIP_NO_LDS_TWIDDLES") != nullptr;
+    A.single_transforms = getenv("FHE_HIP_NO_PAIRED_TRANSFORMS") != nullptr;
+    A.paired_everywhere = getenv("FHE_HIP_PAIRED_TRANSFORMS") != nullptr;
     fn(A);
     return post_launch(h->stream, "ntt_extprod_kernel");
 }

@@ -21,6 +21,13 @@ constexpr bool lds_keyswitch_split(int elem_bytes, int log_n) { return elem_byte
 // workgroup per CU) it was 1-6 % slower, so that size keeps reading twiddles through L2.
 constexpr bool lds_twiddles_in_lds(int elem_bytes, int log_n) { return elem_bytes == 4 && log_n <= 13; }
 
+// key switching / external product with the digit transforms done two at a time (ntt_keyswitch2_kernel / ntt_extprod2_kernel;
+// two exchange buffers: 66 KiB at N = 2^13, 132 KiB at N = 2^14).  Interleaved A/B on one MI355X (scripts/bench_ab_paired.sh):
+// relinearisation +4 % at N = 8192 and +11 % at N = 16384; external product +4 % at N = 16384 but -1 % at N = 8192 against the
+// one-at-a-time kernel with LDS twiddles, which therefore stays the choice there.
+constexpr bool lds_paired_keyswitch(int elem_bytes, int log_n) { return elem_bytes == 4 && log_n <= 14; }
+constexpr bool lds_paired_extprod(int elem_bytes, int log_n) { return elem_bytes == 4 && log_n == 14; }
+
 struct LdsArgs {
     int op;
     void *r0, *r1, *r2;                  // outputs (forward / inverse: r0 is the in-place buffer)
@@ -35,6 +42,8 @@ struct LdsArgs {
     const void *kb1 = nullptr, *ka1 = nullptr;
     const uint32_t *shifts = nullptr;
     bool global_twiddles = false;        // testing aid (FHE_HIP_NO_LDS_TWIDDLES=1): run the variant that reads twiddles from L2
+    bool single_transforms = false;      // testing aid (FHE_HIP_NO_PAIRED_TRANSFORMS=1): one digit transform at a time
+    bool paired_everywhere = false;      // testing aid (FHE_HIP_PAIRED_TRANSFORMS=1): the paired external product at every size that has it
 };
 
 typedef void (*lds_launch_fn)(const LdsArgs &);

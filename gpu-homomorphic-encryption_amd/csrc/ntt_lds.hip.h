@@ -431,6 +431,49 @@ __device__ __forceinline__ void fwd_core(typename F::E (&x)[32], typename F::E *
     lds_get<PatZ<LOGN>>(lds, tid, x);
     fwd_stages<F, LOGN, PatZ<LOGN>, C::REM - 1, 0, TWL>(x, tid, t2, P);
 }
+// ---- two forward transforms under ONE modulus at once ------------------------------------------------------------------
+// The key-switch and external-product kernels transform many digit polynomials under the same modulus.  Doing two of them
+// in lock step shares every twiddle load (one load feeds two butterflies), every barrier and every LDS wait between the two,
+// and doubles the independent work in flight per wave -- for the same register budget as holding the undecomposed limb
+// beside one digit polynomial.  x0 / x1 use their own exchange buffers lds0 / lds1.
+template <class F, int LOGN, class Pat, int KHI, int KLO>
+__device__ __forceinline__ void fwd_stages2(typename F::E (&x0)[32], typename F::E (&x1)[32], uint32_t tid, const typename F::TW *__restrict__ tw,
+                                            const Limb<F> &P) {
+    const uint32_t base = Pat::TW_UNIFORM ? 0u : Pat::base(tid);
+#pragma unroll
+    for (int k = KHI; k >= KLO; k--) {
+        const int b = Pat::BIT0 + k;
+        const typename F::TW *p = tw + ((1u << (LOGN - 1 - b)) + (base >> (b + 1)));
+#pragma unroll
+        for (int r = 0; r < 32; r++) {
+            if (r & (1 << k)) continue;
+            const typename F::TW w = p[Pat::off(r) >> (b + 1)];
+            F::fwd_bfly(x0[r], x0[r | (1 << k)], w, P);
+            F::fwd_bfly(x1[r], x1[r | (1 << k)], w, P);
+        }
+    }
+}
+// PRESYNC as in fwd_core: the barrier that ends the previous transforms' use of the exchange buffers sits after the first group.
+template <class F, int LOGN, bool PRESYNC = false>
+__device__ __forceinline__ void fwd_core2(typename F::E (&x0)[32], typename F::E (&x1)[32], typename F::E *lds0, typename F::E *lds1, uint32_t tid,
+                                          const Limb<F> &P) {
+    using C = NttCfg<LOGN>;
+    fwd_stages2<F, LOGN, PatA<LOGN>, 4, 0>(x0, x1, tid, P.tw, P);
+    if constexpr (PRESYNC) __syncthreads();
+    lds_put<PatA<LOGN>>(lds0, tid, x0);
+    lds_put<PatA<LOGN>>(lds1, tid, x1);
+    __syncthreads();
+    lds_get<PatM<LOGN>>(lds0, tid, x0);
+    lds_get<PatM<LOGN>>(lds1, tid, x1);
+    fwd_stages2<F, LOGN, PatM<LOGN>, 4, 0>(x0, x1, tid, P.tw, P);
+    lds_put<PatM<LOGN>>(lds0, tid, x0);
+    lds_put<PatM<LOGN>>(lds1, tid, x1);
+    __syncthreads();
+    lds_get<PatZ<LOGN>>(lds0, tid, x0);
+    lds_get<PatZ<LOGN>>(lds1, tid, x1);
+    fwd_stages2<F, LOGN, PatZ<LOGN>, C::REM - 1, 0>(x0, x1, tid, P.tw, P);
+}
+
 // NTT values in pattern Z, in [0, 2q)  ->  coefficients in pattern A, in [0, 2q), scaled by the (ninv..) constants
 template <class F, int LOGN, bool TWL = false, bool PRESYNC = false>
 __device__ __forceinline__ void inv_core(typename F::E (&x)[32], typename F::E *lds, uint32_t tid, const Limb<F> &P,
@@ -940,6 +983,138 @@ ntt_extprod_kernel(char *__restrict__ out0, char *__restrict__ out1, const char 
         __syncthreads();
         store_from_lds<F, LOGN>((half ? out1 : out0) + (size_t)p * (C::N * 32), lds, tid);
     }
+}
+
+// ---- paired forms of the key-switch and external-product kernels (4-byte residues) --------------------------------------
+// Same results as ntt_keyswitch_kernel / ntt_extprod_kernel (SPLIT = false); the digit polynomials are transformed two at a
+// time (fwd_core2).  Registers: acc0, acc1, d0, d1 (the undecomposed limb is not kept: both digits of a pair are cut from the
+// freshly loaded values).  LDS: two exchange buffers (66 KiB at N = 8192: two workgroups per CU; 132 KiB at N = 16384: one).
+template <class F>
+__device__ __forceinline__ void mac_keys(typename F::E (&acc0)[32], typename F::E (&acc1)[32], const typename F::E (&d)[32],
+                                         const typename F::E *__restrict__ kb, const typename F::E *__restrict__ ka, size_t tbl, uint32_t tid,
+                                         uint32_t T, const Limb<F> &P) {
+    using E = typename F::E;
+    constexpr int VPL = 16 / sizeof(E), NCH = 32 / VPL;
+    typedef E VecE __attribute__((ext_vector_type(VPL)));
+    const VecE *pb = reinterpret_cast<const VecE *>(kb + tbl) + tid, *pa = reinterpret_cast<const VecE *>(ka + tbl) + tid;
+#pragma unroll
+    for (int c = 0; c < NCH; c++) {
+        const VecE vb = pb[c * T], va = pa[c * T];
+#pragma unroll
+        for (int e = 0; e < VPL; e++) {
+            const int r = c * VPL + e;
+            acc0[r] = F::pw_add(acc0[r], F::pw_mul(vb[e], d[r], P.q, P.qinv), P.q, P.q2);
+            acc1[r] = F::pw_add(acc1[r], F::pw_mul(va[e], d[r], P.q, P.qinv), P.q, P.q2);
+        }
+    }
+}
+// inverse transform of one accumulator, + the addend polynomial, store  (shared tail of the paired kernels)
+template <class F, int LOGN, bool PRESYNC>
+__device__ __forceinline__ void finish_component(typename F::E (&acc)[32], typename F::E (&tmp)[32], typename F::E *lds, uint32_t tid, const Limb<F> &P,
+                                                 const char *addend, char *dst) {
+    using C = NttCfg<LOGN>;
+    inv_core<F, LOGN, false, PRESYNC>(acc, lds, tid, P, P.ninv, P.ninv_s, P.ninvw, P.ninvw_s);
+    load_A<F, LOGN>(addend, tid, tmp);
+#pragma unroll
+    for (int r = 0; r < 32; r++) acc[r] = F::ew_add(F::canon_inv(acc[r], P.q), tmp[r], P.q);
+    lds_put<PatA<LOGN>>(lds, tid, acc);
+    __syncthreads();
+    store_from_lds<F, LOGN>(dst, lds, tid);
+}
+
+template <class F, int LOGN, int MINW = 1>
+__global__ void __launch_bounds__(NttCfg<LOGN>::T, MINW)
+ntt_keyswitch2_kernel(char *__restrict__ c0, char *__restrict__ c1, const char *__restrict__ c2,
+                      const typename F::E *__restrict__ kb, const typename F::E *__restrict__ ka,
+                      const Limb<F> *__restrict__ limbs, uint32_t L, uint32_t K, uint32_t w) {
+    using C = NttCfg<LOGN>;
+    using E = typename F::E;
+    __shared__ E lds[2 * C::LDS_ELEMS];
+    const uint32_t tid = threadIdx.x, bid = blockIdx.x, full = (gridDim.x / (8 * L)) * (8 * L);
+    uint32_t b, i;                                        // XCD-aware map, as in ntt_keyswitch_kernel
+    if (bid < full) { const uint32_t s = bid >> 3; b = (bid & 7) + 8 * (s / L); i = s % L; }
+    else { b = bid / L; i = bid % L; }
+    const uint32_t p = b * L + i;
+    const Limb<F> P = limbs[i];
+    const char *ct2 = c2 + (size_t)b * L * (C::N * 32);
+    E acc0[32], acc1[32], d0[32], d1[32];
+#pragma unroll
+    for (int r = 0; r < 32; r++) { acc0[r] = 0; acc1[r] = 0; }
+    const uint32_t LK = L * K;
+    uint32_t jk = 0;
+    for (; jk + 1 < LK; jk += 2) {
+        const uint32_t j0 = jk / K, k0 = jk % K, j1 = (jk + 1) / K, k1 = (jk + 1) % K;
+        load_A<F, LOGN>(ct2 + (size_t)j1 * (C::N * 32), tid, d1);
+        if (j0 == j1) {
+#pragma unroll
+            for (int r = 0; r < 32; r++) d0[r] = F::digit(d1[r], k0 * w, w);
+        } else {
+            load_A<F, LOGN>(ct2 + (size_t)j0 * (C::N * 32), tid, d0);
+#pragma unroll
+            for (int r = 0; r < 32; r++) d0[r] = F::digit(d0[r], k0 * w, w);
+        }
+#pragma unroll
+        for (int r = 0; r < 32; r++) d1[r] = F::digit(d1[r], k1 * w, w);
+        fwd_core2<F, LOGN, true>(d0, d1, lds, lds + C::LDS_ELEMS, tid, P);
+        mac_keys<F>(acc0, acc1, d0, kb, ka, ((size_t)jk * L + i) * C::N, tid, C::T, P);
+        mac_keys<F>(acc0, acc1, d1, kb, ka, ((size_t)(jk + 1) * L + i) * C::N, tid, C::T, P);
+    }
+    if (jk < LK) {                                        // odd number of digit polynomials: the last one alone
+        const uint32_t j0 = jk / K, k0 = jk % K;
+        load_A<F, LOGN>(ct2 + (size_t)j0 * (C::N * 32), tid, d0);
+#pragma unroll
+        for (int r = 0; r < 32; r++) d0[r] = F::digit(d0[r], k0 * w, w);
+        fwd_core<F, LOGN, false, true>(d0, lds, tid, P);
+        mac_keys<F>(acc0, acc1, d0, kb, ka, ((size_t)jk * L + i) * C::N, tid, C::T, P);
+    }
+    finish_component<F, LOGN, true>(acc0, d0, lds, tid, P, c0 + (size_t)p * (C::N * 32), c0 + (size_t)p * (C::N * 32));
+    __syncthreads();
+    finish_component<F, LOGN, false>(acc1, d0, lds, tid, P, c1 + (size_t)p * (C::N * 32), c1 + (size_t)p * (C::N * 32));
+}
+
+template <class F, int LOGN, int MINW = 1>
+__global__ void __launch_bounds__(NttCfg<LOGN>::T, MINW)
+ntt_extprod2_kernel(char *__restrict__ out0, char *__restrict__ out1, const char *__restrict__ in0, const char *__restrict__ in1,
+                    const uint32_t *__restrict__ shifts,
+                    const typename F::E *__restrict__ kb0, const typename F::E *__restrict__ ka0,
+                    const typename F::E *__restrict__ kb1, const typename F::E *__restrict__ ka1,
+                    const Limb<F> *__restrict__ limbs, uint32_t L, uint32_t K, uint32_t w) {
+    using C = NttCfg<LOGN>;
+    using E = typename F::E;
+    __shared__ E lds[2 * C::LDS_ELEMS];
+    const uint32_t tid = threadIdx.x, bid = blockIdx.x, full = (gridDim.x / (8 * L)) * (8 * L);
+    uint32_t b, i;
+    if (bid < full) { const uint32_t s = bid >> 3; b = (bid & 7) + 8 * (s / L); i = s % L; }
+    else { b = bid / L; i = bid % L; }
+    const uint32_t p = b * L + i;
+    const Limb<F> P = limbs[i];
+    const uint32_t a = shifts[b] & (2 * C::N - 1);
+    const size_t ct = (size_t)b * L * (C::N * 32);
+    E acc0[32], acc1[32], d0[32], d1[32];
+#pragma unroll
+    for (int r = 0; r < 32; r++) { acc0[r] = 0; acc1[r] = 0; }
+    const uint32_t LK = L * K, G = 2 * LK;                // digit polynomials of component 0, then of component 1: always an even number
+    for (uint32_t g = 0; g < G; g += 2) {
+        const uint32_t c0i = g / LK, jk0 = g % LK, j0 = jk0 / K, k0 = jk0 % K;
+        const uint32_t c1i = (g + 1) / LK, jk1 = (g + 1) % LK, j1 = jk1 / K, k1 = jk1 % K;
+        load_monomial_A<F, LOGN>((c1i ? in1 : in0) + ct + (size_t)j1 * (C::N * 32), lds, tid, a, limbs[j1].q, d1);
+        if (c0i == c1i && j0 == j1) {
+#pragma unroll
+            for (int r = 0; r < 32; r++) d0[r] = F::digit(d1[r], k0 * w, w);
+        } else {
+            load_monomial_A<F, LOGN>((c0i ? in1 : in0) + ct + (size_t)j0 * (C::N * 32), lds, tid, a, limbs[j0].q, d0);
+#pragma unroll
+            for (int r = 0; r < 32; r++) d0[r] = F::digit(d0[r], k0 * w, w);
+        }
+#pragma unroll
+        for (int r = 0; r < 32; r++) d1[r] = F::digit(d1[r], k1 * w, w);
+        fwd_core2<F, LOGN, true>(d0, d1, lds, lds + C::LDS_ELEMS, tid, P);
+        mac_keys<F>(acc0, acc1, d0, c0i ? kb1 : kb0, c0i ? ka1 : ka0, ((size_t)jk0 * L + i) * C::N, tid, C::T, P);
+        mac_keys<F>(acc0, acc1, d1, c1i ? kb1 : kb0, c1i ? ka1 : ka0, ((size_t)jk1 * L + i) * C::N, tid, C::T, P);
+    }
+    finish_component<F, LOGN, true>(acc0, d0, lds, tid, P, in0 + (size_t)p * (C::N * 32), out0 + (size_t)p * (C::N * 32));
+    __syncthreads();
+    finish_component<F, LOGN, false>(acc1, d0, lds, tid, P, in1 + (size_t)p * (C::N * 32), out1 + (size_t)p * (C::N * 32));
 }
 
 // ---- relinearisation building blocks (general path; the fused key-switch kernels are above) --------------------

@@ -321,8 +321,12 @@ def _random_keys(moduli, n, count, seed):
 @pytest.mark.parametrize("n,spec,w,batch", [(2048, [40961], 8, 2), (8192, ("bits", 30, 4), 16, 3), (4096, ("bits", 30, 2), 30, 2),
                                             (4096, ("bits", 40, 3), 20, 2), (2048, ("bits", 60, 2), 32, 1), (256, ("bits", 250, 2), 64, 2),
                                             (1024, [12289], 16, 2)])
-def test_relinearize_matches_oracle(eng, oracle, n, spec, w, batch):
-    """FHEContext::relinearize semantics (DESIGN.md, N1) on every width class, arbitrary key material."""
+@pytest.mark.parametrize("single", [False, True])
+def test_relinearize_matches_oracle(eng, oracle, monkeypatch, n, spec, w, batch, single):
+    """FHEContext::relinearize semantics (DESIGN.md, N1) on every width class, arbitrary key material; digit transforms two at a
+    time (default where available) and one at a time."""
+    if single:
+        monkeypatch.setenv("FHE_HIP_NO_PAIRED_TRANSFORMS", "1")
     moduli = _moduli(spec, n); L = len(moduli)
     e = eng.RnsNttEngine(n, moduli); rp = oracle.RnsPlan(n, moduli)
     K = e.relin_num_digits(w)
@@ -697,12 +701,17 @@ def test_blind_rotate_step_matches_oracle(eng, oracle, n, spec, w, batch):
 @pytest.mark.parametrize("n,spec,w,batch,steps", [(8192, ("bits", 30, 4), 16, 9, 3), (2048, ("bits", 30, 2), 30, 17, 2), (16384, ("bits", 30, 3), 16, 2, 1),
                                                   (32768, ("bits", 30, 2), 16, 2, 2), (4096, ("bits", 40, 2), 20, 3, 3), (2048, ("bits", 60, 2), 32, 2, 2),
                                                   (256, ("bits", 250, 1), 64, 2, 2)])
-@pytest.mark.parametrize("fused", [True, False])
+@pytest.mark.parametrize("fused", [True, False, "paired", "single"])
 def test_blind_rotate_loop_matches_oracle(eng, oracle, monkeypatch, n, spec, w, batch, steps, fused):
     """fhe_blind_rotate: `steps` external products with a different RGSW row set and different shifts per step; the fused
-    one-launch-per-step path (ping-pong buffers, odd and even step counts) and the general composition both equal the oracle."""
-    if not fused:
+    one-launch-per-step path (ping-pong buffers, odd and even step counts; default kernel choice, digit transforms two at a time
+    everywhere, one at a time everywhere) and the general composition all equal the oracle."""
+    if fused is False:
         monkeypatch.setenv("FHE_HIP_NO_FUSED_BLIND_ROTATE", "1")
+    elif fused == "paired":
+        monkeypatch.setenv("FHE_HIP_PAIRED_TRANSFORMS", "1")
+    elif fused == "single":
+        monkeypatch.setenv("FHE_HIP_NO_PAIRED_TRANSFORMS", "1")
     moduli = _moduli(spec, n); L = len(moduli)
     e = eng.RnsNttEngine(n, moduli); rp = oracle.RnsPlan(n, moduli)
     K = e.relin_num_digits(w)
