@@ -499,6 +499,8 @@ static int lds_run(fhe_rns_ntt *h, int op, void *r0, void *r1, void *r2, const v
     fhe_dev::lds_launch_fn fn = fhe_dev::lds_lookup(h->width == FHE_WIDTH_32 ? 32 : h->width == FHE_WIDTH_52 ? 52 : 64, (int)h->log_n);
     if (!fn) return fail(FHE_ERR_UNSUPPORTED, "transform size outside the LDS-resident range");
     fhe_dev::LdsArgs A{op, r0, r1, r2, a0, a1, b0, b1, h->d_limbs, h->L, polys, h->stream};
+    A.single_transforms = getenv("FHE_HIP_NO_PAIRED_TRANSFORMS") != nullptr;
+    A.paired_everywhere = getenv("FHE_HIP_PAIRED_TRANSFORMS") != nullptr;
     fn(A);
     return post_launch(h->stream, what);
 }
