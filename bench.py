@@ -175,7 +175,7 @@ def main():
         dSh = pkg.DeviceBuffer.from_numpy(shifts)
         step = lambda: eng.blind_rotate(rows0, rows1, ins[0], ins[1], dSh, outs[0], outs[1], B)
         # per external product: read the accumulator pair, write the accumulator pair (keys are shared by the whole batch)
-        unit, units_per_poly_bytes, kernel = "extprod/s", 4 * R, "ntt_extprod_kernel"
+        unit, units_per_poly_bytes, kernel = "extprod/s", 4 * R, "ntt_extprod"
         what = (f"blind-rotation inner loop: {R} steps acc += ExtProd((X^a - 1) acc, RGSW_s) per accumulator, w = {args.decomp_bits}, "
                 f"{2 * L * K} rows per RGSW, {args.br_keys} RGSW keys cycled")
     else:
@@ -186,13 +186,13 @@ def main():
         if args.op == "relin":
             step = lambda: eng.relinearize(rk, ins[0], ins[1], ins[2], B)
             # read c2 once (re-reads by the L limb workgroups are cache traffic), read + write c0 and c1
-            unit, units_per_poly_bytes, kernel = "relin/s", 5, "ntt_keyswitch_kernel"
+            unit, units_per_poly_bytes, kernel = "relin/s", 5, "ntt_keyswitch"
             what = f"relinearisation: key switching of c2 into (c0, c1), w = {args.decomp_bits}, {L * K} key levels"
         else:
             def step():
                 eng.ct_multiply(outs[0], outs[1], outs[2], ins[0], ins[1], ins[2], ins[3], B)
                 eng.relinearize(rk, outs[0], outs[1], outs[2], B)
-            unit, units_per_poly_bytes, kernel = "ct-mul/s", 12, "ntt_ct_multiply_kernel+ntt_keyswitch_kernel"
+            unit, units_per_poly_bytes, kernel = "ct-mul/s", 12, "ntt_ct_multiply_kernel+ntt_keyswitch"
             what = f"full ciphertext multiply: tensor product (7*S) + relinearisation (5*S), w = {args.decomp_bits}"
 
     def barrier():
