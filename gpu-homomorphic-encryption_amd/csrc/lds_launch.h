@@ -23,8 +23,8 @@ constexpr bool lds_twiddles_in_lds(int elem_bytes, int log_n) { return elem_byte
 
 // key switching / external product with the digit transforms done two at a time (ntt_keyswitch2_kernel / ntt_extprod2_kernel;
 // two exchange buffers: 66 KiB at N = 2^13, 132 KiB at N = 2^14).  Interleaved A/B on one MI355X (scripts/bench_ab_paired.sh):
-// relinearisation +4 % at N = 8192 and +11 % at N = 16384; external product +4 % at N = 16384 but -1 % at N = 8192 against the
-// one-at-a-time kernel with LDS twiddles, which therefore stays the choice there.
+// relinearisation +5 % at N = 8192 and +17 % at N = 16384; external product +5 % at N = 16384, level at N = 8192 with the
+// one-at-a-time kernel with LDS twiddles, which stays the choice there.
 constexpr bool lds_paired_keyswitch(int elem_bytes, int log_n) { return elem_bytes == 4 && log_n <= 14; }
 constexpr bool lds_paired_extprod(int elem_bytes, int log_n) { return elem_bytes == 4 && log_n == 14; }
 

@@ -497,6 +497,48 @@ __device__ __forceinline__ void inv_core(typename F::E (&x)[32], typename F::E *
     inv_last_stage<F>(x, P.q, P.q2, ninv, ninv_s, ninvw, ninvw_s);
 }
 
+// two inverse transforms in lock step (see fwd_core2)
+template <class F, int LOGN, class Pat, int KLO, int KHI>
+__device__ __forceinline__ void inv_stages2(typename F::E (&x0)[32], typename F::E (&x1)[32], uint32_t tid, const typename F::TW *__restrict__ itw,
+                                            const Limb<F> &P) {
+    const uint32_t base = Pat::TW_UNIFORM ? 0u : Pat::base(tid);
+#pragma unroll
+    for (int k = KLO; k <= KHI; k++) {
+        const int b = Pat::BIT0 + k;
+        const typename F::TW *p = itw + ((1u << (LOGN - 1 - b)) + (base >> (b + 1)));
+#pragma unroll
+        for (int r = 0; r < 32; r++) {
+            if (r & (1 << k)) continue;
+            const typename F::TW w = p[Pat::off(r) >> (b + 1)];
+            F::inv_bfly(x0[r], x0[r | (1 << k)], w, P);
+            F::inv_bfly(x1[r], x1[r | (1 << k)], w, P);
+        }
+    }
+}
+template <class F, int LOGN, bool PRESYNC = false>
+__device__ __forceinline__ void inv_core2(typename F::E (&x0)[32], typename F::E (&x1)[32], typename F::E *lds0, typename F::E *lds1, uint32_t tid,
+                                          const Limb<F> &P, typename F::E ninv, typename F::E ninv_s, typename F::E ninvw, typename F::E ninvw_s) {
+    using C = NttCfg<LOGN>;
+    inv_stages2<F, LOGN, PatZ<LOGN>, 0, 4>(x0, x1, tid, P.itw, P);
+    F::regroup(x0, P.q, P.qinv); F::regroup(x1, P.q, P.qinv);
+    if constexpr (PRESYNC) __syncthreads();
+    lds_put<PatZ<LOGN>>(lds0, tid, x0);
+    lds_put<PatZ<LOGN>>(lds1, tid, x1);
+    __syncthreads();
+    lds_get<PatY<LOGN>>(lds0, tid, x0);
+    lds_get<PatY<LOGN>>(lds1, tid, x1);
+    inv_stages2<F, LOGN, PatY<LOGN>, 0, 4>(x0, x1, tid, P.itw, P);
+    F::regroup(x0, P.q, P.qinv); F::regroup(x1, P.q, P.qinv);
+    lds_put<PatY<LOGN>>(lds0, tid, x0);
+    lds_put<PatY<LOGN>>(lds1, tid, x1);
+    __syncthreads();
+    lds_get<PatA<LOGN>>(lds0, tid, x0);
+    lds_get<PatA<LOGN>>(lds1, tid, x1);
+    inv_stages2<F, LOGN, PatA<LOGN>, 5 - C::REM, 3>(x0, x1, tid, P.itw, P);
+    inv_last_stage<F>(x0, P.q, P.q2, ninv, ninv_s, ninvw, ninvw_s);
+    inv_last_stage<F>(x1, P.q, P.q2, ninv, ninv_s, ninvw, ninvw_s);
+}
+
 // =========================================================================================================
 // Kernels.  grid.x = batch * L workgroups; workgroup p handles polynomial p (limb p % L).
 // =========================================================================================================
@@ -1008,18 +1050,24 @@ __device__ __forceinline__ void mac_keys(typename F::E (&acc0)[32], typename F::
         }
     }
 }
-// inverse transform of one accumulator, + the addend polynomial, store  (shared tail of the paired kernels)
-template <class F, int LOGN, bool PRESYNC>
-__device__ __forceinline__ void finish_component(typename F::E (&acc)[32], typename F::E (&tmp)[32], typename F::E *lds, uint32_t tid, const Limb<F> &P,
-                                                 const char *addend, char *dst) {
-    using C = NttCfg<LOGN>;
-    inv_core<F, LOGN, false, PRESYNC>(acc, lds, tid, P, P.ninv, P.ninv_s, P.ninvw, P.ninvw_s);
-    load_A<F, LOGN>(addend, tid, tmp);
+// both accumulators back to the coefficient domain in lock step, + the addend polynomials, store  (tail of the paired kernels)
+template <class F, int LOGN>
+__device__ __forceinline__ void finish_pair(typename F::E (&acc0)[32], typename F::E (&acc1)[32], typename F::E (&t0)[32], typename F::E (&t1)[32],
+                                            typename F::E *lds0, typename F::E *lds1, uint32_t tid, const Limb<F> &P,
+                                            const char *add0, const char *add1, char *dst0, char *dst1) {
+    load_A<F, LOGN>(add0, tid, t0);            // issued first: the HBM latency hides under the inverse transforms
+    load_A<F, LOGN>(add1, tid, t1);
+    inv_core2<F, LOGN, true>(acc0, acc1, lds0, lds1, tid, P, P.ninv, P.ninv_s, P.ninvw, P.ninvw_s);
 #pragma unroll
-    for (int r = 0; r < 32; r++) acc[r] = F::ew_add(F::canon_inv(acc[r], P.q), tmp[r], P.q);
-    lds_put<PatA<LOGN>>(lds, tid, acc);
+    for (int r = 0; r < 32; r++) {
+        acc0[r] = F::ew_add(F::canon_inv(acc0[r], P.q), t0[r], P.q);
+        acc1[r] = F::ew_add(F::canon_inv(acc1[r], P.q), t1[r], P.q);
+    }
+    lds_put<PatA<LOGN>>(lds0, tid, acc0);
+    lds_put<PatA<LOGN>>(lds1, tid, acc1);
     __syncthreads();
-    store_from_lds<F, LOGN>(dst, lds, tid);
+    store_from_lds<F, LOGN>(dst0, lds0, tid);
+    store_from_lds<F, LOGN>(dst1, lds1, tid);
 }
 
 template <class F, int LOGN, int MINW = 1>
@@ -1067,9 +1115,8 @@ ntt_keyswitch2_kernel(char *__restrict__ c0, char *__restrict__ c1, const char *
         fwd_core<F, LOGN, false, true>(d0, lds, tid, P);
         mac_keys<F>(acc0, acc1, d0, kb, ka, ((size_t)jk * L + i) * C::N, tid, C::T, P);
     }
-    finish_component<F, LOGN, true>(acc0, d0, lds, tid, P, c0 + (size_t)p * (C::N * 32), c0 + (size_t)p * (C::N * 32));
-    __syncthreads();
-    finish_component<F, LOGN, false>(acc1, d0, lds, tid, P, c1 + (size_t)p * (C::N * 32), c1 + (size_t)p * (C::N * 32));
+    finish_pair<F, LOGN>(acc0, acc1, d0, d1, lds, lds + C::LDS_ELEMS, tid, P, c0 + (size_t)p * (C::N * 32), c1 + (size_t)p * (C::N * 32),
+                         c0 + (size_t)p * (C::N * 32), c1 + (size_t)p * (C::N * 32));
 }
 
 template <class F, int LOGN, int MINW = 1>
@@ -1112,9 +1159,8 @@ ntt_extprod2_kernel(char *__restrict__ out0, char *__restrict__ out1, const char
         mac_keys<F>(acc0, acc1, d0, c0i ? kb1 : kb0, c0i ? ka1 : ka0, ((size_t)jk0 * L + i) * C::N, tid, C::T, P);
         mac_keys<F>(acc0, acc1, d1, c1i ? kb1 : kb0, c1i ? ka1 : ka0, ((size_t)jk1 * L + i) * C::N, tid, C::T, P);
     }
-    finish_component<F, LOGN, true>(acc0, d0, lds, tid, P, in0 + (size_t)p * (C::N * 32), out0 + (size_t)p * (C::N * 32));
-    __syncthreads();
-    finish_component<F, LOGN, false>(acc1, d0, lds, tid, P, in1 + (size_t)p * (C::N * 32), out1 + (size_t)p * (C::N * 32));
+    finish_pair<F, LOGN>(acc0, acc1, d0, d1, lds, lds + C::LDS_ELEMS, tid, P, in0 + (size_t)p * (C::N * 32), in1 + (size_t)p * (C::N * 32),
+                         out0 + (size_t)p * (C::N * 32), out1 + (size_t)p * (C::N * 32));
 }
 
 // ---- relinearisation building blocks (general path; the fused key-switch kernels are above) --------------------

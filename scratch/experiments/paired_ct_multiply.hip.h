@@ -1,5 +1,5 @@
 // paired_ct_multiply.hip.h -- EXPERIMENT, not adopted: the tensor product with (a0, a1), (b0, b1) and (c0, c1) transformed two at a
-// time (fwd_core2 from the product header + the inv_core2 below).  Parity-green on the MI355X; interleaved A/B against
+// time (fwd_core2 / inv_core2 from the product header).  Parity-green on the MI355X; interleaved A/B against
 // ntt_ct_multiply_kernel: N = 8192, 4 limbs, batch 1024: 776 K vs 798 K ct-mul/s (-3 %); N = 16384, 6 limbs, batch 128: 207 K vs 209 K;
 // N = 4096: 1.503 M vs 1.510 M.  The tensor product is HBM-bound (0.74 of 8 TB/s), so sharing twiddle loads and barriers buys
 // nothing and the second exchange buffer + 256 VGPRs cost a little.  (The same pairing pays for key switching: +4..11 %.)
@@ -7,47 +7,6 @@
 #pragma once
 
 namespace fhe_dev {
-
-// two inverse transforms in lock step (see fwd_core2)
-template <class F, int LOGN, class Pat, int KLO, int KHI>
-__device__ __forceinline__ void inv_stages2(typename F::E (&x0)[32], typename F::E (&x1)[32], uint32_t tid, const typename F::TW *__restrict__ itw,
-                                            const Limb<F> &P) {
-    const uint32_t base = Pat::TW_UNIFORM ? 0u : Pat::base(tid);
-#pragma unroll
-    for (int k = KLO; k <= KHI; k++) {
-        const int b = Pat::BIT0 + k;
-        const typename F::TW *p = itw + ((1u << (LOGN - 1 - b)) + (base >> (b + 1)));
-#pragma unroll
-        for (int r = 0; r < 32; r++) {
-            if (r & (1 << k)) continue;
-            const typename F::TW w = p[Pat::off(r) >> (b + 1)];
-            F::inv_bfly(x0[r], x0[r | (1 << k)], w, P);
-            F::inv_bfly(x1[r], x1[r | (1 << k)], w, P);
-        }
-    }
-}
-template <class F, int LOGN>
-__device__ __forceinline__ void inv_core2(typename F::E (&x0)[32], typename F::E (&x1)[32], typename F::E *lds0, typename F::E *lds1, uint32_t tid,
-                                          const Limb<F> &P, typename F::E ninv, typename F::E ninv_s, typename F::E ninvw, typename F::E ninvw_s) {
-    using C = NttCfg<LOGN>;
-    inv_stages2<F, LOGN, PatZ<LOGN>, 0, 4>(x0, x1, tid, P.itw, P);
-    F::regroup(x0, P.q, P.qinv); F::regroup(x1, P.q, P.qinv);
-    lds_put<PatZ<LOGN>>(lds0, tid, x0);
-    lds_put<PatZ<LOGN>>(lds1, tid, x1);
-    __syncthreads();
-    lds_get<PatY<LOGN>>(lds0, tid, x0);
-    lds_get<PatY<LOGN>>(lds1, tid, x1);
-    inv_stages2<F, LOGN, PatY<LOGN>, 0, 4>(x0, x1, tid, P.itw, P);
-    F::regroup(x0, P.q, P.qinv); F::regroup(x1, P.q, P.qinv);
-    lds_put<PatY<LOGN>>(lds0, tid, x0);
-    lds_put<PatY<LOGN>>(lds1, tid, x1);
-    __syncthreads();
-    lds_get<PatA<LOGN>>(lds0, tid, x0);
-    lds_get<PatA<LOGN>>(lds1, tid, x1);
-    inv_stages2<F, LOGN, PatA<LOGN>, 5 - C::REM, 3>(x0, x1, tid, P.itw, P);
-    inv_last_stage<F>(x0, P.q, P.q2, ninv, ninv_s, ninvw, ninvw_s);
-    inv_last_stage<F>(x1, P.q, P.q2, ninv, ninv_s, ninvw, ninvw_s);
-}
 
 // The tensor product with its transforms done two at a time (fwd_core2 / inv_core2): (a0, a1) and (b0, b1) forward, (c0, c1)
 // inverse, c2 alone.  Same results as ntt_ct_multiply_kernel; two exchange buffers.
