@@ -500,7 +500,6 @@ static int lds_run(fhe_rns_ntt *h, int op, void *r0, void *r1, void *r2, const v
     if (!fn) return fail(FHE_ERR_UNSUPPORTED, "transform size outside the LDS-resident range");
     fhe_dev::LdsArgs A{op, r0, r1, r2, a0, a1, b0, b1, h->d_limbs, h->L, polys, h->stream};
     A.single_transforms = getenv("FHE_HIP_NO_PAIRED_TRANSFORMS") != nullptr;
-    A.paired_everywhere = getenv("FHE_HIP_PAIRED_TRANSFORMS") != nullptr;
     fn(A);
     return post_launch(h->stream, what);
 }
@@ -807,7 +806,6 @@ extern "C" int fhe_ct_relinearize(fhe_rns_ntt_t *h, const fhe_relin_keys_t *rk, 
         A.kb = rk->d_pkb; A.ka = rk->d_pka; A.K = rk->K; A.w = rk->decomp_bits;
         A.global_twiddles = getenv("FHE_HIP_NO_LDS_TWIDDLES") != nullptr;
     A.single_transforms = getenv("FHE_HIP_NO_PAIRED_TRANSFORMS") != nullptr;
-    A.paired_everywhere = getenv("FHE_HIP_PAIRED_TRANSFORMS") != nullptr;
         fn(A);
         return post_launch(h->stream, "ntt_keyswitch_kernel");
     }
@@ -990,7 +988,6 @@ static int blind_rotate_step_fused(fhe_rns_ntt_t *h, const fhe_relin_keys_t *r0,
     A.kb = r0->d_pkb; A.ka = r0->d_pka; A.kb1 = r1->d_pkb; A.ka1 = r1->d_pka; A.K = r0->K; A.w = r0->decomp_bits; A.shifts = d_shifts;
     A.global_twiddles = getenv("FHE_HIP_NO_LDS_TWIDDLES") != nullptr;
     A.single_transforms = getenv("FHE_HIP_NO_PAIRED_TRANSFORMS") != nullptr;
-    A.paired_everywhere = getenv("FHE_HIP_PAIRED_TRANSFORMS") != nullptr;
     fn(A);
     return post_launch(h->stream, "ntt_extprod_kernel");
 }

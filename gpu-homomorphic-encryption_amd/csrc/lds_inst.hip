@@ -66,8 +66,8 @@ void CAT(lds_launch_, FHE_FIELD, FHE_LOGN)(const LdsArgs &A) {
                 hipLaunchKernelGGL((ntt_extprod_kernel<F, LOGN, 2, true>), dim3(A.polys * 2), block, 0, A.stream, (char *)A.r0, (char *)A.r1,
                                    (const char *)A.a0, (const char *)A.a1, A.shifts, (const E *)A.kb, (const E *)A.ka, (const E *)A.kb1,
                                    (const E *)A.ka1, limbs, A.L, A.K, A.w);
-            } else if ((lds_paired_extprod(sizeof(E), LOGN) || (A.paired_everywhere && lds_paired_keyswitch(sizeof(E), LOGN))) && !A.single_transforms) {
-                if constexpr (lds_paired_keyswitch(sizeof(E), LOGN))
+            } else if (lds_paired_extprod(sizeof(E), LOGN) && !A.single_transforms) {
+                if constexpr (lds_paired_extprod(sizeof(E), LOGN))
                     hipLaunchKernelGGL((ntt_extprod2_kernel<F, LOGN, 2>), grid, block, 0, A.stream, (char *)A.r0, (char *)A.r1,
                                        (const char *)A.a0, (const char *)A.a1, A.shifts, (const E *)A.kb, (const E *)A.ka, (const E *)A.kb1,
                                        (const E *)A.ka1, limbs, A.L, A.K, A.w);

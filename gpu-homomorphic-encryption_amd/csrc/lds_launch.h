@@ -22,11 +22,11 @@ constexpr bool lds_keyswitch_split(int elem_bytes, int log_n) { return elem_byte
 constexpr bool lds_twiddles_in_lds(int elem_bytes, int log_n) { return elem_bytes == 4 && log_n <= 13; }
 
 // key switching / external product with the digit transforms done two at a time (ntt_keyswitch2_kernel / ntt_extprod2_kernel;
-// two exchange buffers: 66 KiB at N = 2^13, 132 KiB at N = 2^14).  Interleaved A/B on one MI355X (scripts/bench_ab_paired.sh):
-// relinearisation +5 % at N = 8192 and +17 % at N = 16384; external product +5 % at N = 16384, level at N = 8192 with the
-// one-at-a-time kernel with LDS twiddles, which stays the choice there.
+// two exchange buffers: 66 KiB at N = 2^13, 132 KiB at N = 2^14) and the two products of a pair sharing one Montgomery reduction.
+// Interleaved A/B on one MI355X (scripts/bench_ab_paired.sh) against the one-at-a-time kernels (with LDS twiddles up to N = 2^13):
+// relinearisation +7.5 % at N = 8192 and +17 % at N = 16384; external product +7 % at N = 8192, +13 % at N = 16384, +3.5 % at N = 4096.
 constexpr bool lds_paired_keyswitch(int elem_bytes, int log_n) { return elem_bytes == 4 && log_n <= 14; }
-constexpr bool lds_paired_extprod(int elem_bytes, int log_n) { return elem_bytes == 4 && log_n == 14; }
+constexpr bool lds_paired_extprod(int elem_bytes, int log_n) { return elem_bytes == 4 && log_n <= 14; }
 
 struct LdsArgs {
     int op;
@@ -43,7 +43,6 @@ struct LdsArgs {
     const uint32_t *shifts = nullptr;
     bool global_twiddles = false;        // testing aid (FHE_HIP_NO_LDS_TWIDDLES=1): run the variant that reads twiddles from L2
     bool single_transforms = false;      // testing aid (FHE_HIP_NO_PAIRED_TRANSFORMS=1): one digit transform at a time
-    bool paired_everywhere = false;      // testing aid (FHE_HIP_PAIRED_TRANSFORMS=1): the paired external product at every size that has it
 };
 
 typedef void (*lds_launch_fn)(const LdsArgs &);

@@ -107,6 +107,15 @@ struct F32Base : IntField<Self, uint32_t, TW_> {
         const E m = (E)t * nqinv;
         return (E)(((uint64_t)m * q + t) >> 32);
     }
+    // (a0*b0 + a1*b1) * 2^-32 mod q with ONE reduction: the second product rides on the first as the addend of its
+    // v_mad_u64_u32.  a0, a1 < q (key entries), b0, b1 < 4q (lazy transform outputs), q < 2^30: the sum is < 8q^2 < 2^63 and
+    // the result < 8q^2 / 2^32 + q < 3q; one conditional subtraction brings it to [0, 2q).  4 multiply-class instructions
+    // for two products instead of 6, and one accumulation instead of two.
+    __device__ static __forceinline__ E mont_mul2(E a0, E b0, E a1, E b1, E q, E q2, E nqinv) {
+        const uint64_t t = (uint64_t)a1 * b1 + (uint64_t)a0 * b0;
+        const E m = (E)t * nqinv;
+        return csub<E>((E)(((uint64_t)m * q + t) >> 32), q2);
+    }
     __device__ static __forceinline__ E load_low(const void *container) { return __builtin_nontemporal_load((const E *)container); }
     __device__ static __forceinline__ V16 pack(E v) { V16 o = {v, 0u, 0u, 0u}; return o; }
     __device__ static __forceinline__ uint64_t low(const V16 &v) { return v.x; }
@@ -1050,6 +1059,30 @@ __device__ __forceinline__ void mac_keys(typename F::E (&acc0)[32], typename F::
         }
     }
 }
+// acc0 += kb[t0] .* d0 + kb[t1] .* d1, acc1 likewise with ka: the two products of a pair share one Montgomery reduction (mont_mul2)
+template <class F>
+__device__ __forceinline__ void mac_keys2(typename F::E (&acc0)[32], typename F::E (&acc1)[32], const typename F::E (&d0)[32], const typename F::E (&d1)[32],
+                                          const typename F::E *__restrict__ kb0, const typename F::E *__restrict__ ka0, size_t tbl0,
+                                          const typename F::E *__restrict__ kb1, const typename F::E *__restrict__ ka1, size_t tbl1,
+                                          uint32_t tid, uint32_t T, const Limb<F> &P) {
+    using E = typename F::E;
+    static_assert(sizeof(E) == 4, "mont_mul2 is a 32-bit field operation");
+    constexpr int VPL = 16 / sizeof(E), NCH = 32 / VPL;
+    typedef E VecE __attribute__((ext_vector_type(VPL)));
+    const VecE *pb0 = reinterpret_cast<const VecE *>(kb0 + tbl0) + tid, *pa0 = reinterpret_cast<const VecE *>(ka0 + tbl0) + tid;
+    const VecE *pb1 = reinterpret_cast<const VecE *>(kb1 + tbl1) + tid, *pa1 = reinterpret_cast<const VecE *>(ka1 + tbl1) + tid;
+#pragma unroll
+    for (int c = 0; c < NCH; c++) {
+        const VecE vb0 = pb0[c * T], va0 = pa0[c * T], vb1 = pb1[c * T], va1 = pa1[c * T];
+#pragma unroll
+        for (int e = 0; e < VPL; e++) {
+            const int r = c * VPL + e;
+            acc0[r] = F::pw_add(acc0[r], F::mont_mul2(vb0[e], d0[r], vb1[e], d1[r], P.q, P.q2, P.qinv), P.q, P.q2);
+            acc1[r] = F::pw_add(acc1[r], F::mont_mul2(va0[e], d0[r], va1[e], d1[r], P.q, P.q2, P.qinv), P.q, P.q2);
+        }
+    }
+}
+
 // both accumulators back to the coefficient domain in lock step, + the addend polynomials, store  (tail of the paired kernels)
 template <class F, int LOGN>
 __device__ __forceinline__ void finish_pair(typename F::E (&acc0)[32], typename F::E (&acc1)[32], typename F::E (&t0)[32], typename F::E (&t1)[32],
@@ -1104,8 +1137,7 @@ ntt_keyswitch2_kernel(char *__restrict__ c0, char *__restrict__ c1, const char *
 #pragma unroll
         for (int r = 0; r < 32; r++) d1[r] = F::digit(d1[r], k1 * w, w);
         fwd_core2<F, LOGN, true>(d0, d1, lds, lds + C::LDS_ELEMS, tid, P);
-        mac_keys<F>(acc0, acc1, d0, kb, ka, ((size_t)jk * L + i) * C::N, tid, C::T, P);
-        mac_keys<F>(acc0, acc1, d1, kb, ka, ((size_t)(jk + 1) * L + i) * C::N, tid, C::T, P);
+        mac_keys2<F>(acc0, acc1, d0, d1, kb, ka, ((size_t)jk * L + i) * C::N, kb, ka, ((size_t)(jk + 1) * L + i) * C::N, tid, C::T, P);
     }
     if (jk < LK) {                                        // odd number of digit polynomials: the last one alone
         const uint32_t j0 = jk / K, k0 = jk % K;
@@ -1156,8 +1188,8 @@ ntt_extprod2_kernel(char *__restrict__ out0, char *__restrict__ out1, const char
 #pragma unroll
         for (int r = 0; r < 32; r++) d1[r] = F::digit(d1[r], k1 * w, w);
         fwd_core2<F, LOGN, true>(d0, d1, lds, lds + C::LDS_ELEMS, tid, P);
-        mac_keys<F>(acc0, acc1, d0, c0i ? kb1 : kb0, c0i ? ka1 : ka0, ((size_t)jk0 * L + i) * C::N, tid, C::T, P);
-        mac_keys<F>(acc0, acc1, d1, c1i ? kb1 : kb0, c1i ? ka1 : ka0, ((size_t)jk1 * L + i) * C::N, tid, C::T, P);
+        mac_keys2<F>(acc0, acc1, d0, d1, c0i ? kb1 : kb0, c0i ? ka1 : ka0, ((size_t)jk0 * L + i) * C::N, c1i ? kb1 : kb0, c1i ? ka1 : ka0,
+                     ((size_t)jk1 * L + i) * C::N, tid, C::T, P);
     }
     finish_pair<F, LOGN>(acc0, acc1, d0, d1, lds, lds + C::LDS_ELEMS, tid, P, in0 + (size_t)p * (C::N * 32), in1 + (size_t)p * (C::N * 32),
                          out0 + (size_t)p * (C::N * 32), out1 + (size_t)p * (C::N * 32));

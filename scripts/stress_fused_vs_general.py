@@ -56,12 +56,11 @@ while time.time() - t0 < budget:
     dSh = pkg.DeviceBuffer.from_numpy(shifts)
     want = None
     for rep in range(3):
-        for keyset, env, tag in ((general, "1", "general"), (fused, None, "fused"), (fused, None, "fused-paired")):
-            os.environ.pop("FHE_HIP_NO_PAIRED_TRANSFORMS", None)
-            if tag == "fused-paired":
-                os.environ["FHE_HIP_PAIRED_TRANSFORMS"] = "1"
+        for keyset, env, tag in ((general, "1", "general"), (fused, None, "fused"), (fused, None, "fused-single")):
+            if tag == "fused-single":
+                os.environ["FHE_HIP_NO_PAIRED_TRANSFORMS"] = "1"
             else:
-                os.environ.pop("FHE_HIP_PAIRED_TRANSFORMS", None)
+                os.environ.pop("FHE_HIP_NO_PAIRED_TRANSFORMS", None)
             if env:
                 os.environ["FHE_HIP_NO_FUSED_BLIND_ROTATE"] = env
             else:
@@ -74,7 +73,7 @@ while time.time() - t0 < budget:
                 want = got
             elif not (np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])):
                 print(f"MISMATCH blind_rotate {tag} n={n} bits={bits} L={L} w={w} batch={batch} steps={steps} seed={seed} rep={rep}"); sys.exit(1)
-    os.environ.pop("FHE_HIP_NO_FUSED_BLIND_ROTATE", None); os.environ.pop("FHE_HIP_PAIRED_TRANSFORMS", None)
+    os.environ.pop("FHE_HIP_NO_FUSED_BLIND_ROTATE", None); os.environ.pop("FHE_HIP_NO_PAIRED_TRANSFORMS", None)
     cases += 1
     if cases % 10 == 0:
         print(f"{cases} shapes, {launches} launches, {time.time() - t0:.0f} s", flush=True)

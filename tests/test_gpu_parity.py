@@ -701,15 +701,13 @@ def test_blind_rotate_step_matches_oracle(eng, oracle, n, spec, w, batch):
 @pytest.mark.parametrize("n,spec,w,batch,steps", [(8192, ("bits", 30, 4), 16, 9, 3), (2048, ("bits", 30, 2), 30, 17, 2), (16384, ("bits", 30, 3), 16, 2, 1),
                                                   (32768, ("bits", 30, 2), 16, 2, 2), (4096, ("bits", 40, 2), 20, 3, 3), (2048, ("bits", 60, 2), 32, 2, 2),
                                                   (256, ("bits", 250, 1), 64, 2, 2)])
-@pytest.mark.parametrize("fused", [True, False, "paired", "single"])
+@pytest.mark.parametrize("fused", [True, False, "single"])
 def test_blind_rotate_loop_matches_oracle(eng, oracle, monkeypatch, n, spec, w, batch, steps, fused):
     """fhe_blind_rotate: `steps` external products with a different RGSW row set and different shifts per step; the fused
-    one-launch-per-step path (ping-pong buffers, odd and even step counts; default kernel choice, digit transforms two at a time
-    everywhere, one at a time everywhere) and the general composition all equal the oracle."""
+    one-launch-per-step path (ping-pong buffers, odd and even step counts; digit transforms two at a time -- the default where
+    that kernel exists -- and one at a time) and the general composition all equal the oracle."""
     if fused is False:
         monkeypatch.setenv("FHE_HIP_NO_FUSED_BLIND_ROTATE", "1")
-    elif fused == "paired":
-        monkeypatch.setenv("FHE_HIP_PAIRED_TRANSFORMS", "1")
     elif fused == "single":
         monkeypatch.setenv("FHE_HIP_NO_PAIRED_TRANSFORMS", "1")
     moduli = _moduli(spec, n); L = len(moduli)
