@@ -756,3 +756,80 @@ void orc_poly_mod_switch(orc_u256 *out, const orc_u256 *in, const orc_u256 *old_
 void orc_negacyclic_reduce(orc_u256 *data, const orc_u256 *q, size_t n) {
     for (size_t i = 0; i < n; i++) { orc_u256 t; orc_sub_mod(&t, &data[i], &data[i + n], q); data[i] = t; }
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* Word-sized CPU port of the same polymul (q < 2^62): 64-bit residues, Shoup-style constant    */
+/* multiplication through unsigned __int128.  Same transforms, same outputs as orc_rns_polymul  */
+/* (asserted by the tests); it exists so that bench.py can also quote a CPU baseline that does  */
+/* NOT pay for the reference's 256-bit containers -- the fairer number to hold a GPU against.   */
+/* ------------------------------------------------------------------------------------------ */
+static inline uint64_t mulmod64(uint64_t a, uint64_t b, uint64_t q) { return (uint64_t)((unsigned __int128)a * b % q); }
+static inline uint64_t shoup_mul64(uint64_t x, uint64_t w, uint64_t ws, uint64_t q) {      /* x*w mod q for x < 2q..., w < q, ws = floor(w 2^64 / q) */
+    uint64_t hi = (uint64_t)(((unsigned __int128)x * ws) >> 64);
+    uint64_t r = x * w - hi * q;
+    return r >= q ? r - q : r;
+}
+int orc_rns_polymul_narrow(orc_plan *const *plans, uint32_t L, orc_u256 *r, const orc_u256 *a, const orc_u256 *b, uint32_t batch, int threads) {
+    const uint32_t n = plans[0]->n;
+    for (uint32_t l = 0; l < L; l++) if (plans[l]->q.limbs[1] | plans[l]->q.limbs[2] | plans[l]->q.limbs[3] | (plans[l]->q.limbs[0] >> 62)) return -1;
+    /* per-limb word tables: plain twiddles + Shoup companions */
+    uint64_t **tw = (uint64_t **)malloc(L * sizeof(*tw));
+    for (uint32_t l = 0; l < L; l++) {
+        const orc_plan *p = plans[l]; const uint64_t q = p->q.limbs[0];
+        tw[l] = (uint64_t *)malloc((size_t)4 * n * sizeof(uint64_t));            /* w, ws, iw, iws */
+        for (uint32_t k = 0; k < n; k++) {
+            orc_u256 w, iw; from_mont(p, &w, &p->tw_m[k]); from_mont(p, &iw, &p->itw_m[k]);
+            tw[l][k] = w.limbs[0]; tw[l][n + k] = (uint64_t)(((unsigned __int128)w.limbs[0] << 64) / q);
+            tw[l][2 * n + k] = iw.limbs[0]; tw[l][3 * n + k] = (uint64_t)(((unsigned __int128)iw.limbs[0] << 64) / q);
+        }
+    }
+    threads = clamp_threads(threads);
+    const long total = (long)batch * L;
+    int used = 1;
+#pragma omp parallel num_threads(threads)
+    {
+#pragma omp single
+        used = omp_get_num_threads();
+        uint64_t *x = (uint64_t *)malloc((size_t)2 * n * sizeof(uint64_t)), *y = x + n;
+#pragma omp for schedule(dynamic)
+        for (long pi = 0; pi < total; pi++) {
+            const uint32_t l = (uint32_t)(pi % L);
+            const orc_plan *p = plans[l]; const uint64_t q = p->q.limbs[0];
+            const uint64_t *w = tw[l], *ws = tw[l] + n, *iw = tw[l] + 2 * n, *iws = tw[l] + 3 * n;
+            for (uint32_t j = 0; j < n; j++) { x[j] = a[(size_t)pi * n + j].limbs[0]; y[j] = b[(size_t)pi * n + j].limbs[0]; }
+            for (int which = 0; which < 2; which++) {                            /* forward: natural in, bit-reversed out */
+                uint64_t *v = which ? y : x; uint32_t t = n;
+                for (uint32_t m = 1; m < n; m <<= 1) {
+                    t >>= 1;
+                    for (uint32_t i = 0; i < m; i++) {
+                        const uint64_t W = w[m + i], WS = ws[m + i];
+                        for (uint32_t j = 2 * i * t; j < 2 * i * t + t; j++) {
+                            const uint64_t u = v[j], s = shoup_mul64(v[j + t], W, WS, q);
+                            uint64_t e = u + s; v[j] = e >= q ? e - q : e;
+                            v[j + t] = u >= s ? u - s : u + q - s;
+                        }
+                    }
+                }
+            }
+            for (uint32_t j = 0; j < n; j++) x[j] = mulmod64(x[j], y[j], q);
+            uint32_t t = 1;                                                      /* inverse: bit-reversed in, natural out */
+            for (uint32_t m = n >> 1; m >= 1; m >>= 1) {
+                for (uint32_t i = 0; i < m; i++) {
+                    const uint64_t W = iw[m + i], WS = iws[m + i];
+                    for (uint32_t j = 2 * i * t; j < 2 * i * t + t; j++) {
+                        const uint64_t u = x[j], s = x[j + t];
+                        uint64_t e = u + s; x[j] = e >= q ? e - q : e;
+                        x[j + t] = shoup_mul64(u >= s ? u - s : u + q - s, W, WS, q);
+                    }
+                }
+                t <<= 1;
+            }
+            orc_u256 ninv; from_mont(p, &ninv, &p->n_inv_m);
+            for (uint32_t j = 0; j < n; j++) r[(size_t)pi * n + j] = u256_from(mulmod64(x[j], ninv.limbs[0], q));
+        }
+        free(x);
+    }
+    for (uint32_t l = 0; l < L; l++) free(tw[l]);
+    free(tw);
+    return used;
+}

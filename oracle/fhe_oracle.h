@@ -150,6 +150,9 @@ void orc_sample_uniform(orc_plan *const *plans, uint32_t L, orc_u256 *out, uint6
 /* poly_mod_switch_kernel / negacyclic_reduce_kernel (include/polynomial.cuh:96-110, declared only). */
 void orc_poly_mod_switch(orc_u256 *out, const orc_u256 *in, const orc_u256 *old_q, uint64_t new_q, size_t count);
 void orc_negacyclic_reduce(orc_u256 *data, const orc_u256 *q, size_t n);
+/* Word-sized CPU port of orc_rns_polymul for q < 2^62 (64-bit residues, Shoup constant multiplication): same outputs, a CPU
+ * baseline that does not pay for 256-bit containers.  Returns the number of threads used, -1 if a modulus is too wide. */
+int orc_rns_polymul_narrow(orc_plan *const *plans, uint32_t L, orc_u256 *r, const orc_u256 *a, const orc_u256 *b, uint32_t batch, int threads);
 int orc_max_threads(void);
 
 #ifdef __cplusplus

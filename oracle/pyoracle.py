@@ -73,6 +73,7 @@ def lib():
             "orc_rns_polymul": (ci, [ctypes.POINTER(vp), u32, P, P, P, u32, ci]),
             "orc_ct_multiply": (ci, [ctypes.POINTER(vp), u32] + [P] * 7 + [u32, ci]),
             "orc_max_threads": (ci, []),
+            "orc_rns_polymul_narrow": (ci, [ctypes.POINTER(vp), u32, P, P, P, u32, ci]),
             "orc_sample_uniform_lcg": (None, [P, P, u64, sz]),
             "orc_sample_gaussian_placeholder": (None, [P, P, u64, sz]),
             "orc_ctr_rand": (u64, [u64, u64, u64]),
@@ -293,6 +294,16 @@ class RnsPlan:
         return c0, c1, c2
 
 
+def _rns_polymul_narrow(self, a, b, threads=1):
+    """Word-sized CPU port (q < 2^62) of polymul: same outputs, 64-bit arithmetic."""
+    _chk(a, b); out = np.empty_like(a)
+    used = lib().orc_rns_polymul_narrow(self._arr, self.L, _p(out), _p(a), _p(b), self._batch(a), threads)
+    if used < 0:
+        raise ValueError("polymul_narrow needs moduli below 2^62")
+    self.threads_used = used
+    return out
+
+
 def _rns_relin(self, decomp_bits, c0, c1, c2, keys_b, keys_a, threads=1):
     """c0', c1' (copies) after key switching c2 with the L*K keys (each a [L][n] limb array, coefficient form)."""
     P = ctypes.POINTER(U256)
@@ -363,6 +374,7 @@ def _rns_blind_rotate(self, decomp_bits, acc0, acc1, shifts, rows0_list, rows1_l
     return acc0, acc1
 
 
+RnsPlan.polymul_narrow = _rns_polymul_narrow
 RnsPlan.monomial_mul_sub = _rns_monomial_mul_sub
 RnsPlan.blind_rotate = _rns_blind_rotate
 RnsPlan.blind_rotate_step = _rns_blind_rotate_step

@@ -505,3 +505,15 @@ def test_stockham_stages_equal_the_in_place_forward_kernel(oracle):
         for stage in range(n.bit_length() - 1):
             y = oracle.ref_stockham_stage(y, tw, q, stage)
         assert np.array_equal(y, oracle.ref_forward_kernel(x, oracle.to_limbs(spread), q))
+
+
+def test_word_sized_cpu_port_equals_the_wide_oracle(oracle):
+    """orc_rns_polymul_narrow (64-bit residues) == orc_rns_polymul (256-bit containers) on 30-, 40- and 60-bit primes."""
+    from workload import rns_poly
+    for n, bits, L in [(64, 30, 3), (2048, 40, 2), (1024, 60, 2)]:
+        moduli = nm.ntt_primes(bits, n, L); rp = oracle.RnsPlan(n, moduli)
+        a, b = rns_poly(71, moduli, n, 3), rns_poly(72, moduli, n, 3)
+        assert np.array_equal(rp.polymul_narrow(a, b, threads=2), rp.polymul(a, b, threads=2))
+    with pytest.raises(ValueError):
+        n = 64; moduli = nm.ntt_primes(250, n, 1)
+        oracle.RnsPlan(n, moduli).polymul_narrow(rns_poly(1, moduli, n, 1), rns_poly(2, moduli, n, 1))
