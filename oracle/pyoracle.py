@@ -13,7 +13,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "_build", "libfhe_oracle.so")
+# FHE_ORACLE_ASAN=1 loads the AddressSanitizer / UBSan build (`make -C oracle asan`; run python with LD_PRELOAD=$(gcc -print-file-name=libasan.so))
+_LIB_PATH = os.path.join(_HERE, "_build", "libfhe_oracle_asan.so" if os.environ.get("FHE_ORACLE_ASAN") == "1" else "libfhe_oracle.so")
 _lib = None
 
 
