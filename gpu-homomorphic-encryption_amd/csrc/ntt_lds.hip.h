@@ -72,6 +72,10 @@ struct IntField {
     __device__ static __forceinline__ E canon_inv(E x, E q) { return csub<E>(x, q); }       // [0,2q) -> [0,q)
     // NTT-domain product for the fused kernels: a canonical, b lazy (< 4q); result in [0,2q), carries 2^-W
     __device__ static __forceinline__ E pw_mul(E a, E b, E q, E qinv) { return Self::mont_mul(a, b, q, qinv); }
+    // a0*b0 + a1*b1 in the NTT domain (a* canonical, b* lazy), result in [0,2q), carries 2^-W; F32 overrides it with one shared reduction
+    __device__ static __forceinline__ E pw_mul2(E a0, E b0, E a1, E b1, E q, E q2, E qinv) {
+        return csub<E>(Self::mont_mul(a0, b0, q, qinv) + Self::mont_mul(a1, b1, q, qinv), q2);
+    }
     // [0,2q)+[0,2q) -> [0,2q)
     __device__ static __forceinline__ E pw_add(E a, E b, E, E q2) { return csub<E>(a + b, q2); }
     // element-wise canonical ops
@@ -116,6 +120,7 @@ struct F32Base : IntField<Self, uint32_t, TW_> {
         const E m = (E)t * nqinv;
         return csub<E>((E)(((uint64_t)m * q + t) >> 32), q2);
     }
+    __device__ static __forceinline__ E pw_mul2(E a0, E b0, E a1, E b1, E q, E q2, E nqinv) { return mont_mul2(a0, b0, a1, b1, q, q2, nqinv); }
     __device__ static __forceinline__ E load_low(const void *container) { return __builtin_nontemporal_load((const E *)container); }
     __device__ static __forceinline__ V16 pack(E v) { V16 o = {v, 0u, 0u, 0u}; return o; }
     __device__ static __forceinline__ uint64_t low(const V16 &v) { return v.x; }
@@ -206,6 +211,7 @@ struct F52 {
         return d + l;
     }
     __device__ static __forceinline__ E pw_add(E a, E b, E, E) { return a + b; }
+    __device__ static __forceinline__ E pw_mul2(E a0, E b0, E a1, E b1, E q, E, E qinv) { return pw_mul(a0, b0, q, qinv) + pw_mul(a1, b1, q, qinv); }
     template <class L> __device__ static __forceinline__ E ew_mul(E x, E y, const L &P) { return canon_inv(pw_mul(x, y, P.q, P.qinv), P.q); }
     __device__ static __forceinline__ E ew_add(E x, E y, E q) { E t = x + y; return t >= q ? t - q : t; }
     __device__ static __forceinline__ E ew_sub(E x, E y, E q) { E t = x - y; return t < 0 ? t + q : t; }
@@ -692,13 +698,9 @@ ntt_ct_multiply_kernel(char *__restrict__ c0, char *__restrict__ c1, char *__res
     for (int r = 0; r < 32; r++) {
         E u0 = F::canon_fwd(A0[r], P.q, P.q2, P.qinv), u1 = F::canon_fwd(A1[r], P.q, P.q2, P.qinv);   // canonical a-side
         E v0 = B0[r], v1 = B1[r];                                                             // lazy b-side (< 4q)
-        E t00 = F::pw_mul(u0, v0, P.q, P.qinv);
-        E t01 = F::pw_mul(u0, v1, P.q, P.qinv);
-        E t10 = F::pw_mul(u1, v0, P.q, P.qinv);
-        E t11 = F::pw_mul(u1, v1, P.q, P.qinv);
-        A0[r] = t00;                           // [0,2q)
-        A1[r] = F::pw_add(t01, t10, P.q, P.q2);   // (0,4q) -> [0,2q)
-        B0[r] = t11;
+        A0[r] = F::pw_mul(u0, v0, P.q, P.qinv);                  // [0,2q)
+        A1[r] = F::pw_mul2(u0, v1, u1, v0, P.q, P.q2, P.qinv);   // a0*b1 + a1*b0 with one shared reduction on the 32-bit field
+        B0[r] = F::pw_mul(u1, v1, P.q, P.qinv);
     }
     inv_core<F, LOGN>(A0, lds, tid, P, P.ninv_r, P.ninv_r_s, P.ninvw_r, P.ninvw_r_s);
 #pragma unroll
