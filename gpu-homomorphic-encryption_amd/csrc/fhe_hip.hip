@@ -9,6 +9,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <type_traits>
 #include <utility>
 #include <vector>
 
@@ -243,6 +244,9 @@ struct fhe_rns_ntt {
     void *d_rescale = nullptr;           // RescaleLimb[L-1], built on first use of rescale_drop_last (owned by d_tables)
     void *d_bconv = nullptr;             // ((Q/q_i) mod p_j) * R_j for the most recent base-conversion target (owned by d_tables)
     const void *bconv_target = nullptr;
+    void *d_rescale_w = nullptr;         // word-sized classes: (q_last^-1 mod q_l) as pw operands, E[L-1] (owned by d_tables)
+    void *d_bconv_w_minv = nullptr, *d_bconv_w_mat = nullptr;   // word-sized classes: base-conversion operands for bconv_w_target
+    const void *bconv_w_target = nullptr;
     fhe_dev::CrtBig crt_big;
     int crt_state = 0;                   // 0 = not built, 1 = ready, -1 = Q too large for from_rns (to_rns still fine)
     double cdt_sigma = 0; uint64_t *d_cdt = nullptr; uint32_t cdt_len = 0;   // cumulative table of the last Gaussian sampler call
@@ -899,10 +903,73 @@ extern "C" int fhe_rns_from_rns(fhe_rns_ntt_t *h, void *d_values, const void *d_
 }
 
 
+// "pw operand" of the constant c for limb modulus q of a word-sized class: c * 2^W mod q for the integer fields (so that the
+// Montgomery product with it is the plain product), c itself for the FP64 field
+template <class F> static typename F::E word_operand(uint64_t c, uint64_t q) {
+    using E = typename F::E;
+    if (std::is_same<F, fhe_dev::F52>::value) return (E)c;
+    const unsigned W = 8 * sizeof(E);
+    fhe_host::u128 v = (fhe_host::u128)(c % q);
+    for (unsigned k = 0; k < W; k++) v = (v << 1) % q;
+    return (E)(uint64_t)v;
+}
+static uint64_t inv_mod_u64(uint64_t a, uint64_t q) {       // a^(q-2) mod q, q prime
+    fhe_host::u128 acc = 1, b = a % q; uint64_t e = q - 2;
+    for (; e; e >>= 1) { if (e & 1) acc = acc * b % q; b = b * b % q; }
+    return (uint64_t)acc;
+}
+template <class F>
+static int rescale_word(fhe_rns_ntt *h, void *d_out, const void *d_in, uint32_t batch) {
+    using E = typename F::E; using V = typename F::V16;
+    if (!h->d_rescale_w) {
+        std::vector<E> ops(h->L - 1);
+        const uint64_t ql = h->moduli[h->L - 1].w[0];
+        for (uint32_t l = 0; l + 1 < h->L; l++) { const uint64_t q = h->moduli[l].w[0]; ops[l] = word_operand<F>(inv_mod_u64(ql % q, q), q); }
+        int rc = upload(h, ops, &h->d_rescale_w); if (rc) return rc;
+    }
+    const size_t halves = (size_t)batch * (h->L - 1) * h->n * 2;
+    hipLaunchKernelGGL((fhe_dev::rescale_word_kernel<F>), dim3(ew_grid(halves)), dim3(256), 0, h->stream, (V *)d_out, (const V *)d_in,
+                       (const fhe_dev::Limb<F> *)h->d_limbs, (const E *)h->d_rescale_w, h->L, h->log_n, halves);
+    return post_launch(h->stream, "rescale_word_kernel");
+}
+template <class F>
+static int base_convert_word(fhe_rns_ntt *h, fhe_rns_ntt *t, void *d_out, const void *d_in, uint32_t batch) {
+    using E = typename F::E; using V = typename F::V16;
+    if (h->bconv_w_target != t) {
+        const uint32_t L = h->L, Lp = t->L;
+        std::vector<E> minv(L), mat((size_t)L * Lp);
+        for (uint32_t i = 0; i < L; i++) {
+            const uint64_t qi = h->moduli[i].w[0];
+            fhe_host::u128 Mi = 1;
+            for (uint32_t k = 0; k < L; k++) if (k != i) Mi = Mi * (h->moduli[k].w[0] % qi) % qi;
+            minv[i] = word_operand<F>(inv_mod_u64((uint64_t)Mi, qi), qi);
+            for (uint32_t j = 0; j < Lp; j++) {
+                const uint64_t pj = t->moduli[j].w[0];
+                fhe_host::u128 m = 1;
+                for (uint32_t k = 0; k < L; k++) if (k != i) m = m * (h->moduli[k].w[0] % pj) % pj;
+                mat[(size_t)i * Lp + j] = word_operand<F>((uint64_t)m, pj);
+            }
+        }
+        int rc;
+        if ((rc = upload(h, minv, &h->d_bconv_w_minv)) || (rc = upload(h, mat, &h->d_bconv_w_mat))) return rc;   // earlier tables stay owned by d_tables
+        h->bconv_w_target = t;
+    }
+    const size_t halves = (size_t)batch * t->L * h->n * 2;
+    hipLaunchKernelGGL((fhe_dev::base_convert_word_kernel<F>), dim3(ew_grid(halves)), dim3(256), 0, h->stream, (V *)d_out, (const V *)d_in,
+                       (const fhe_dev::Limb<F> *)h->d_limbs, h->L, (const fhe_dev::Limb<F> *)t->d_limbs, t->L, (const E *)h->d_bconv_w_minv,
+                       (const E *)h->d_bconv_w_mat, h->log_n, halves);
+    return post_launch(h->stream, "base_convert_word_kernel");
+}
+
 extern "C" int fhe_rns_rescale_drop_last(fhe_rns_ntt_t *h, void *d_out, const void *d_in, uint32_t batch) {
     int rc = check_call(h, batch, "rescale_drop_last"); if (rc) return rc;
     if (!d_out || !d_in || d_out == d_in) return fail(FHE_ERR_INVALID_ARG, "rescale_drop_last: null or aliased argument");
     if (h->L < 2) return fail(FHE_ERR_INVALID_ARG, "rescale_drop_last: needs at least two primes");
+    if (!getenv("FHE_HIP_NO_WORD_CONVERSIONS")) {       // word-sized classes: streaming kernels on the field type
+        if (h->width == FHE_WIDTH_32) return rescale_word<fhe_dev::F32>(h, d_out, d_in, batch);
+        if (h->width == FHE_WIDTH_52) return rescale_word<fhe_dev::F52>(h, d_out, d_in, batch);
+        if (h->width == FHE_WIDTH_64) return rescale_word<fhe_dev::F64>(h, d_out, d_in, batch);
+    }
     if ((rc = ensure_crt(h))) return rc;
     if (!h->d_rescale) {
         std::vector<fhe_dev::RescaleLimb> rs(h->L - 1);
@@ -926,6 +993,11 @@ extern "C" int fhe_rns_fast_base_convert(fhe_rns_ntt_t *h, fhe_rns_ntt_t *target
     int rc = check_call(h, batch, "fast_base_convert"); if (rc) return rc;
     if (!target || !d_out || !d_in || d_out == d_in) return fail(FHE_ERR_INVALID_ARG, "fast_base_convert: null or aliased argument");
     if (target->n != h->n) return fail(FHE_ERR_INVALID_ARG, "fast_base_convert: source and target engines differ in degree");
+    if (h->width == target->width && h->width != FHE_WIDTH_256 && !getenv("FHE_HIP_NO_WORD_CONVERSIONS")) {
+        if (h->width == FHE_WIDTH_32) return base_convert_word<fhe_dev::F32>(h, target, d_out, d_in, batch);
+        if (h->width == FHE_WIDTH_52) return base_convert_word<fhe_dev::F52>(h, target, d_out, d_in, batch);
+        return base_convert_word<fhe_dev::F64>(h, target, d_out, d_in, batch);
+    }
     if ((rc = ensure_crt(h)) || (rc = ensure_crt(target))) return rc;
     if (h->bconv_target != target) {
         std::vector<fhe_dev::u256> mat((size_t)h->L * target->L);

@@ -1248,6 +1248,70 @@ relin_mac_kernel(typename F::V16 *__restrict__ acc0, typename F::V16 *__restrict
     }
 }
 
+// ---- RNS conversions on word-sized residues (row N2): rounded drop of the last prime, Bajard fast base conversion -----------
+// The container-level kernels in ntt256.hip.h do these through 256-bit Montgomery products for every width class; for word-sized
+// classes the same arithmetic fits the field type and the kernels are streaming kernels.  Constants are "pw operands"
+// (c * 2^W mod q for the integer fields, c for F52) so that canon(pw_mul(constant, x)) is the plain product c * x mod q.
+template <class F>
+__device__ __forceinline__ typename F::E mul_const(typename F::E cop, typename F::E x, const Limb<F> &P) {
+    return F::canon_inv(F::pw_mul(cop, x, P.q, P.qinv), P.q);
+}
+// v < 2^63 (a canonical residue of another prime of the same class) reduced modulo q
+template <class F>
+__device__ __forceinline__ typename F::E reduce_into(typename F::E v, typename F::E q) {
+    if constexpr (sizeof(typename F::E) == 4) return v % q;           // 32-bit modulo instead of the 64-bit one of from_u64
+    else return F::from_u64((uint64_t)v, q);
+}
+// out[b][l][x] = (in[b][l][x] - [c]_{q_l}) * q_last^-1 mod q_l, c = the CENTRED residue of in[b][L-1][x] modulo q_last
+// (RNSContext::mod_switch_rns, include/rns.cuh:44, declared only).  One 16-byte half container of the output per lane.
+template <class F>
+__global__ void __launch_bounds__(256)
+rescale_word_kernel(typename F::V16 *__restrict__ out, const typename F::V16 *__restrict__ in, const Limb<F> *__restrict__ limbs,
+                    const typename F::E *__restrict__ inv_ops, uint32_t L, uint32_t log_n, size_t out_halves) {
+    using E = typename F::E;
+    const size_t stride = (size_t)gridDim.x * blockDim.x, n = (size_t)1 << log_n;
+    const E q_last = limbs[L - 1].q, half = (E)(((uint64_t)q_last - 1) >> 1);              // floor(q_last / 2), q_last odd
+    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < out_halves; g += stride) {
+        E o = 0;
+        if (!(g & 1)) {
+            const size_t c = g >> 1, x = c & (n - 1), pl = c >> log_n, b = pl / (L - 1);
+            const uint32_t l = (uint32_t)(pl % (L - 1));
+            const Limb<F> &P = limbs[l];
+            const E cl = F::load_low(in + (((b * L + (L - 1)) << log_n) + x) * 2);
+            const E xl = F::load_low(in + (((b * L + l) << log_n) + x) * 2);
+            const bool neg = cl > half;
+            const E m = reduce_into<F>(neg ? q_last - cl : cl, P.q);
+            const E r = (neg && m != (E)0) ? P.q - m : m;
+            o = mul_const<F>(inv_ops[l], F::ew_sub(xl, r, P.q), P);
+        }
+        __builtin_nontemporal_store(F::pack(o), out + g);
+    }
+}
+// out[b][j][x] = sum_i ([x_i * (Q/q_i)^-1]_{q_i} mod p_j) * ((Q/q_i) mod p_j) mod p_j   (RNSContext::base_extend, include/rns.cuh:47-48, declared only).
+// minv_ops[i] is an operand of source limb i, mat_ops[i * Lp + j] an operand of target limb j.  One half container of the output per lane.
+template <class F>
+__global__ void __launch_bounds__(256)
+base_convert_word_kernel(typename F::V16 *__restrict__ out, const typename F::V16 *__restrict__ in, const Limb<F> *__restrict__ src, uint32_t L,
+                         const Limb<F> *__restrict__ dst, uint32_t Lp, const typename F::E *__restrict__ minv_ops,
+                         const typename F::E *__restrict__ mat_ops, uint32_t log_n, size_t out_halves) {
+    using E = typename F::E;
+    const size_t stride = (size_t)gridDim.x * blockDim.x, n = (size_t)1 << log_n;
+    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < out_halves; g += stride) {
+        E o = 0;
+        if (!(g & 1)) {
+            const size_t c = g >> 1, x = c & (n - 1), pl = c >> log_n, b = pl / Lp;
+            const uint32_t j = (uint32_t)(pl % Lp);
+            const Limb<F> &D = dst[j];
+            for (uint32_t i = 0; i < L; i++) {
+                const Limb<F> &S = src[i];
+                const E ti = mul_const<F>(minv_ops[i], F::load_low(in + (((b * L + i) << log_n) + x) * 2), S);
+                o = F::ew_add(o, mul_const<F>(mat_ops[(size_t)i * Lp + j], reduce_into<F>(ti, D.q), D), D.q);
+            }
+        }
+        __builtin_nontemporal_store(F::pack(o), out + g);
+    }
+}
+
 // ---- blind-rotation building block: out[b][l][x] = ((X^shift[b] - 1) * in[b][l])[x] over Z_q[x]/(x^n + 1), shift in [0, 2n) ----
 // (FHEContext::blind_rotate is only declared in the reference, include/fhe.cuh:139.)  One 16-byte half container per lane;
 // the rotated read is a shifted contiguous run, so it stays coalesced.

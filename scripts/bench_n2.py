@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Timing of the RNS conversion kernels (row N2): to_rns, from_rns, rescale_drop_last, fast_base_convert.  HIP-event timing on the
+engine stream; algorithmic bytes = containers read + written.   usage: bench_n2.py [n] [limbs] [bits] [batch]"""
+import importlib
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+pkg = importlib.import_module("gpu-homomorphic-encryption_amd")
+from workload import rns_poly  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
+L = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+bits = int(sys.argv[3]) if len(sys.argv) > 3 else 30
+B = int(sys.argv[4]) if len(sys.argv) > 4 else 1024
+moduli = pkg.find_ntt_primes(bits, n, L + 2)
+eng = pkg.RnsNttEngine(n, moduli[:L]); tgt = pkg.RnsNttEngine(n, moduli[L:])
+S1 = 32 * n                                   # one limb of one polynomial
+x = rns_poly(3, moduli[:L], n, B)
+dX = pkg.DeviceBuffer.from_numpy(x)
+dV = pkg.DeviceBuffer(B * S1); dY = pkg.DeviceBuffer(B * L * S1); dZ = pkg.DeviceBuffer(B * 2 * S1); dW = pkg.DeviceBuffer(B * (L - 1) * S1)
+
+
+def timed(fn, bytes_moved, name, reps=10):
+    fn(); pkg.capi.sync()
+    t = pkg.Timer(); t.start(eng)
+    for _ in range(reps):
+        fn()
+    t.stop(eng); pkg.capi.sync()
+    ms = t.elapsed_ms() / reps
+    print(f"{name:22s} {ms:8.3f} ms  {bytes_moved / ms / 1e6:8.1f} GB/s  ({B / ms * 1e3:10.0f} polys/s)")
+
+
+print(f"N={n} L={L} {bits}-bit batch={B} width_class={eng.width_class}")
+timed(lambda: eng.from_rns(dV, dX, B), B * (L + 1) * S1, "from_rns (CRT)")
+timed(lambda: eng.to_rns(dY, dV, B), B * (L + 1) * S1, "to_rns")
+timed(lambda: eng.rescale_drop_last(dW, dX, B), B * (2 * L - 1) * S1, "rescale_drop_last")
+timed(lambda: eng.fast_base_convert(tgt, dZ, dX, B), B * (L + 2) * S1, "fast_base_convert L->2")
+timed(lambda: eng.poly_add(dY, dX, dX, B), B * 3 * L * S1, "poly_add (reference)")

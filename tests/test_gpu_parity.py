@@ -636,9 +636,13 @@ def test_largest_lds_size_tensor_and_keyswitch(eng, oracle):
     assert np.array_equal(c[0].download(a0.shape), r0) and np.array_equal(c[1].download(a0.shape), r1)
 
 
-@pytest.mark.parametrize("n,bits,L", [(8192, 30, 4), (2048, 60, 3), (64, 120, 2), (4096, 40, 6), (1024, 30, 2)])
-def test_rescale_drop_last_matches_oracle(eng, oracle, n, bits, L):
-    """Modulus switching by dropping the last prime (rounded division), then the result is usable by an engine on L-1 primes."""
+@pytest.mark.parametrize("n,bits,L", [(8192, 30, 4), (2048, 60, 3), (64, 120, 2), (4096, 40, 6), (1024, 30, 2), (16384, 30, 6), (2048, 62, 2)])
+@pytest.mark.parametrize("word", [True, False])
+def test_rescale_drop_last_matches_oracle(eng, oracle, monkeypatch, n, bits, L, word):
+    """Modulus switching by dropping the last prime (rounded division), then the result is usable by an engine on L-1 primes.
+    word = True: the streaming kernels on the field type (word-sized classes); False: the container-level 256-bit kernels."""
+    if not word:
+        monkeypatch.setenv("FHE_HIP_NO_WORD_CONVERSIONS", "1")
     moduli = nm.ntt_primes(bits, n, L)
     e = eng.RnsNttEngine(n, moduli); rp = oracle.RnsPlan(n, moduli)
     batch = 3
@@ -655,8 +659,13 @@ def test_rescale_drop_last_matches_oracle(eng, oracle, n, bits, L):
         eng.RnsNttEngine(n, moduli[:1]).rescale_drop_last(dOut, dIn, 1)
 
 
-@pytest.mark.parametrize("n,bits,L,bits2,Lp", [(8192, 30, 4, 30, 5), (2048, 30, 3, 60, 2), (1024, 60, 2, 40, 3), (64, 120, 2, 250, 1)])
-def test_fast_base_conversion_matches_oracle(eng, oracle, n, bits, L, bits2, Lp):
+@pytest.mark.parametrize("n,bits,L,bits2,Lp", [(8192, 30, 4, 30, 5), (2048, 30, 3, 60, 2), (1024, 60, 2, 40, 3), (64, 120, 2, 250, 1), (4096, 40, 3, 40, 2),
+                                               (2048, 60, 2, 60, 3), (16384, 30, 6, 30, 2)])
+@pytest.mark.parametrize("word", [True, False])
+def test_fast_base_conversion_matches_oracle(eng, oracle, monkeypatch, n, bits, L, bits2, Lp, word):
+    """word = True: same-class word-sized bases take the streaming kernel on the field type; mixed classes and word = False the 256-bit one."""
+    if not word:
+        monkeypatch.setenv("FHE_HIP_NO_WORD_CONVERSIONS", "1")
     src = nm.ntt_primes(bits, n, L)
     dst = [p for p in nm.ntt_primes(bits2, n, Lp + L) if p not in src][:Lp]
     e, t = eng.RnsNttEngine(n, src), eng.RnsNttEngine(n, dst)
