@@ -247,6 +247,8 @@ struct fhe_rns_ntt {
     void *d_rescale_w = nullptr;         // word-sized classes: (q_last^-1 mod q_l) as pw operands, E[L-1] (owned by d_tables)
     void *d_bconv_w_minv = nullptr, *d_bconv_w_mat = nullptr;   // word-sized classes: base-conversion operands for bconv_w_target
     const void *bconv_w_target = nullptr;
+    void *d_from_rns_w_minv = nullptr, *d_from_rns_w_M = nullptr;   // integer word classes: CRT operands and Q / q_l (owned by d_tables)
+    void *d_to_rns_w = nullptr;          // integer word classes: 2^(W k) mod q_l as pw operands, E[L][256 / W] (owned by d_tables)
     fhe_dev::CrtBig crt_big;
     int crt_state = 0;                   // 0 = not built, 1 = ready, -1 = Q too large for from_rns (to_rns still fine)
     double cdt_sigma = 0; uint64_t *d_cdt = nullptr; uint32_t cdt_len = 0;   // cumulative table of the last Gaussian sampler call
@@ -882,27 +884,6 @@ static int ensure_crt(fhe_rns_ntt *h) {
     h->crt_state = fits ? 1 : -1;
     return FHE_OK;
 }
-extern "C" int fhe_rns_to_rns(fhe_rns_ntt_t *h, void *d_rns, const void *d_values, uint32_t batch) {
-    int rc = check_call(h, batch, "to_rns"); if (rc) return rc;
-    if (!d_rns || !d_values || d_rns == d_values) return fail(FHE_ERR_INVALID_ARG, "to_rns: null or aliased argument");
-    if ((rc = ensure_crt(h))) return rc;
-    const size_t count = (size_t)batch * h->n;
-    hipLaunchKernelGGL(fhe_dev::to_rns_kernel, dim3(ew_grid(count)), dim3(256), 0, h->stream, (fhe_dev::u256 *)d_rns, (const fhe_dev::u256 *)d_values,
-                       (const fhe_dev::CrtLimb *)h->d_crt, h->L, h->log_n, count);
-    return post_launch(h->stream, "to_rns_kernel");
-}
-extern "C" int fhe_rns_from_rns(fhe_rns_ntt_t *h, void *d_values, const void *d_rns, uint32_t batch) {
-    int rc = check_call(h, batch, "from_rns"); if (rc) return rc;
-    if (!d_rns || !d_values || d_rns == d_values) return fail(FHE_ERR_INVALID_ARG, "from_rns: null or aliased argument");
-    if ((rc = ensure_crt(h))) return rc;
-    if (h->crt_state < 0) return fail(FHE_ERR_UNSUPPORTED, "from_rns: the product of the moduli must be below 2^255 to fit a 256-bit container");
-    const size_t count = (size_t)batch * h->n;
-    hipLaunchKernelGGL(fhe_dev::from_rns_kernel, dim3(ew_grid(count)), dim3(256), 0, h->stream, (fhe_dev::u256 *)d_values, (const fhe_dev::u256 *)d_rns,
-                       (const fhe_dev::CrtLimb *)h->d_crt, h->crt_big, h->L, h->log_n, count);
-    return post_launch(h->stream, "from_rns_kernel");
-}
-
-
 // "pw operand" of the constant c for limb modulus q of a word-sized class: c * 2^W mod q for the integer fields (so that the
 // Montgomery product with it is the plain product), c itself for the FP64 field
 template <class F> static typename F::E word_operand(uint64_t c, uint64_t q) {
@@ -918,6 +899,78 @@ static uint64_t inv_mod_u64(uint64_t a, uint64_t q) {       // a^(q-2) mod q, q 
     for (; e; e >>= 1) { if (e & 1) acc = acc * b % q; b = b * b % q; }
     return (uint64_t)acc;
 }
+template <class F>
+static int to_rns_word(fhe_rns_ntt *h, void *d_rns, const void *d_values, uint32_t batch) {
+    using E = typename F::E; using V = typename F::V16;
+    constexpr uint32_t NW = 32 / sizeof(E), W = 8 * sizeof(E);
+    if (!h->d_to_rns_w) {
+        std::vector<E> ops((size_t)h->L * NW);
+        for (uint32_t l = 0; l < h->L; l++) {
+            const uint64_t q = h->moduli[l].w[0];
+            fhe_host::u128 p = 1 % q;
+            for (uint32_t k = 0; k < NW; k++) {
+                ops[(size_t)l * NW + k] = word_operand<F>((uint64_t)p, q);
+                for (uint32_t t = 0; t < W; t++) p = (p << 1) % q;              // 2^(W (k+1)) mod q
+            }
+        }
+        int rc = upload(h, ops, &h->d_to_rns_w); if (rc) return rc;
+    }
+    const size_t halves = (size_t)batch * h->L * h->n * 2;
+    hipLaunchKernelGGL((fhe_dev::to_rns_word_kernel<F>), dim3(ew_grid(halves)), dim3(256), 0, h->stream, (V *)d_rns, (const V *)d_values,
+                       (const fhe_dev::Limb<F> *)h->d_limbs, (const E *)h->d_to_rns_w, h->L, h->log_n, halves);
+    return post_launch(h->stream, "to_rns_word_kernel");
+}
+extern "C" int fhe_rns_to_rns(fhe_rns_ntt_t *h, void *d_rns, const void *d_values, uint32_t batch) {
+    int rc = check_call(h, batch, "to_rns"); if (rc) return rc;
+    if (!d_rns || !d_values || d_rns == d_values) return fail(FHE_ERR_INVALID_ARG, "to_rns: null or aliased argument");
+    if (!getenv("FHE_HIP_NO_WORD_CONVERSIONS")) {       // integer word classes: a streaming kernel on the field type
+        if (h->width == FHE_WIDTH_32) return to_rns_word<fhe_dev::F32>(h, d_rns, d_values, batch);
+        if (h->width == FHE_WIDTH_64) return to_rns_word<fhe_dev::F64>(h, d_rns, d_values, batch);
+    }
+    if ((rc = ensure_crt(h))) return rc;
+    const size_t count = (size_t)batch * h->n;
+    hipLaunchKernelGGL(fhe_dev::to_rns_kernel, dim3(ew_grid(count)), dim3(256), 0, h->stream, (fhe_dev::u256 *)d_rns, (const fhe_dev::u256 *)d_values,
+                       (const fhe_dev::CrtLimb *)h->d_crt, h->L, h->log_n, count);
+    return post_launch(h->stream, "to_rns_kernel");
+}
+template <class F>
+static int from_rns_word(fhe_rns_ntt *h, void *d_values, const void *d_rns, uint32_t batch) {
+    using E = typename F::E; using V = typename F::V16;
+    if (!h->d_from_rns_w_minv) {
+        const uint32_t L = h->L;
+        std::vector<E> minv(L); std::vector<fhe_dev::u256> Ms(L);
+        for (uint32_t l = 0; l < L; l++) {
+            const uint64_t q = h->moduli[l].w[0];
+            U256 Mi(1); fhe_host::u128 Mi_mod_q = 1;
+            for (uint32_t k = 0; k < L; k++) if (k != l) { U256 t; mul_checked(t, Mi, h->moduli[k]); Mi = t; Mi_mod_q = Mi_mod_q * (h->moduli[k].w[0] % q) % q; }
+            minv[l] = word_operand<F>(inv_mod_u64((uint64_t)Mi_mod_q, q), q);
+            std::memcpy(Ms[l].l, Mi.w, 32);
+        }
+        int rc;
+        if ((rc = upload(h, minv, &h->d_from_rns_w_minv)) || (rc = upload(h, Ms, &h->d_from_rns_w_M))) return rc;
+    }
+    const size_t count = (size_t)batch * h->n;
+    hipLaunchKernelGGL((fhe_dev::from_rns_word_kernel<F>), dim3(ew_grid(count)), dim3(256), 0, h->stream, (fhe_dev::u256 *)d_values, (const V *)d_rns,
+                       (const fhe_dev::Limb<F> *)h->d_limbs, (const E *)h->d_from_rns_w_minv, (const fhe_dev::u256 *)h->d_from_rns_w_M, h->crt_big.Q,
+                       h->L, h->log_n, count);
+    return post_launch(h->stream, "from_rns_word_kernel");
+}
+extern "C" int fhe_rns_from_rns(fhe_rns_ntt_t *h, void *d_values, const void *d_rns, uint32_t batch) {
+    int rc = check_call(h, batch, "from_rns"); if (rc) return rc;
+    if (!d_rns || !d_values || d_rns == d_values) return fail(FHE_ERR_INVALID_ARG, "from_rns: null or aliased argument");
+    if ((rc = ensure_crt(h))) return rc;
+    if (h->crt_state < 0) return fail(FHE_ERR_UNSUPPORTED, "from_rns: the product of the moduli must be below 2^255 to fit a 256-bit container");
+    if (!getenv("FHE_HIP_NO_WORD_CONVERSIONS")) {       // integer word classes: word x 256-bit accumulation instead of 256-bit Montgomery products
+        if (h->width == FHE_WIDTH_32) return from_rns_word<fhe_dev::F32>(h, d_values, d_rns, batch);
+        if (h->width == FHE_WIDTH_64) return from_rns_word<fhe_dev::F64>(h, d_values, d_rns, batch);
+    }
+    const size_t count = (size_t)batch * h->n;
+    hipLaunchKernelGGL(fhe_dev::from_rns_kernel, dim3(ew_grid(count)), dim3(256), 0, h->stream, (fhe_dev::u256 *)d_values, (const fhe_dev::u256 *)d_rns,
+                       (const fhe_dev::CrtLimb *)h->d_crt, h->crt_big, h->L, h->log_n, count);
+    return post_launch(h->stream, "from_rns_kernel");
+}
+
+
 template <class F>
 static int rescale_word(fhe_rns_ntt *h, void *d_out, const void *d_in, uint32_t batch) {
     using E = typename F::E; using V = typename F::V16;

@@ -26,6 +26,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "u256_dev.h"
+
 namespace fhe_dev {
 
 typedef uint32_t v4u32 __attribute__((ext_vector_type(4)));   // native vectors: accepted by the nontemporal builtins
@@ -1309,6 +1311,73 @@ base_convert_word_kernel(typename F::V16 *__restrict__ out, const typename F::V1
             }
         }
         __builtin_nontemporal_store(F::pack(o), out + g);
+    }
+}
+
+// rns[b][l][x] = values[b][x] mod q_l for ANY 256-bit value (RNS_NTTEngine::to_rns, include/ntt.cuh:114-115, declared only), integer
+// fields: the value is read as 256 / W words of W bits and reduced as sum_k word_k * (2^(W k) mod q_l); pow_ops[l * NW + k] is the
+// pw operand of 2^(W k) mod q_l, and a word needs no reduction of its own (operand < q, word < 2^W: the product is < q 2^W).
+template <class F>
+__global__ void __launch_bounds__(256)
+to_rns_word_kernel(typename F::V16 *__restrict__ rns, const typename F::V16 *__restrict__ values, const Limb<F> *__restrict__ limbs,
+                   const typename F::E *__restrict__ pow_ops, uint32_t L, uint32_t log_n, size_t out_halves) {
+    using E = typename F::E;
+    constexpr int NW = 32 / sizeof(E), HW = NW / 2;                    // words per container / per 16-byte half
+    typedef E VecE __attribute__((ext_vector_type(HW)));
+    const size_t stride = (size_t)gridDim.x * blockDim.x, n = (size_t)1 << log_n;
+    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < out_halves; g += stride) {
+        E o = 0;
+        if (!(g & 1)) {
+            const size_t c = g >> 1, x = c & (n - 1), pl = c >> log_n, b = pl / L;
+            const uint32_t l = (uint32_t)(pl % L);
+            const Limb<F> &P = limbs[l];
+            const VecE *v = reinterpret_cast<const VecE *>(values + ((b << log_n) + x) * 2);
+            const VecE lo = v[0], hi = v[1];
+            const E *ops = pow_ops + (size_t)l * NW;
+#pragma unroll
+            for (int k = 0; k < HW; k++) {
+                o = F::ew_add(o, mul_const<F>(ops[k], lo[k], P), P.q);
+                o = F::ew_add(o, mul_const<F>(ops[HW + k], hi[k], P), P.q);
+            }
+        }
+        __builtin_nontemporal_store(F::pack(o), rns + g);
+    }
+}
+
+// values[b][x] = CRT of the L residues, in [0, Q)  (RNS_NTTEngine::from_rns, include/ntt.cuh:116-117, declared only), integer word
+// classes: sum_l [x_l * (Q/q_l)^-1]_{q_l} * (Q/q_l) is accumulated as word x 256-bit products in a 320-bit register array (the sum is
+// below L * Q) and brought into [0, Q) by at most L - 1 subtractions.  One lane per value; Mi[l] = Q / q_l as a plain integer.
+template <class F>
+__global__ void __launch_bounds__(256)
+from_rns_word_kernel(u256 *__restrict__ values, const typename F::V16 *__restrict__ rns, const Limb<F> *__restrict__ limbs,
+                     const typename F::E *__restrict__ minv_ops, const u256 *__restrict__ Mi, u256 Q, uint32_t L, uint32_t log_n, size_t count) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x, n = (size_t)1 << log_n;
+    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < count; g += stride) {
+        const size_t b = g >> log_n, x = g & (n - 1);
+        uint64_t acc[5] = {0, 0, 0, 0, 0};
+        for (uint32_t l = 0; l < L; l++) {
+            const uint64_t t = (uint64_t)mul_const<F>(minv_ops[l], F::load_low(rns + (((b * L + l) << log_n) + x) * 2), limbs[l]);
+            const u256 M = Mi[l];
+            u128_t c = 0;
+#pragma unroll
+            for (int i = 0; i < 4; i++) { c += (u128_t)t * M.l[i] + acc[i]; acc[i] = (uint64_t)c; c >>= 64; }
+            acc[4] += (uint64_t)c;
+        }
+        for (uint32_t it = 0; it < L; it++) {                          // acc < L * Q
+            bool ge = acc[4] != 0;
+            if (!ge) {
+                ge = true;
+#pragma unroll
+                for (int i = 3; i >= 0; i--) { if (acc[i] != Q.l[i]) { ge = acc[i] > Q.l[i]; break; } }
+            }
+            if (!ge) break;
+            uint64_t borrow = 0;
+#pragma unroll
+            for (int i = 0; i < 4; i++) { u128_t d = (u128_t)acc[i] - Q.l[i] - borrow; acc[i] = (uint64_t)d; borrow = (uint64_t)(d >> 64) & 1; }
+            acc[4] -= borrow;
+        }
+        u256 r; r.l[0] = acc[0]; r.l[1] = acc[1]; r.l[2] = acc[2]; r.l[3] = acc[3];
+        store_u256(values + g, r);
     }
 }
 

@@ -471,9 +471,13 @@ def test_repeated_calls_are_deterministic(eng):
 
 
 # ------------------------------------------------------------------------------------ RNS entry / exit (row a18)
-@pytest.mark.parametrize("n,bits,L", [(8192, 30, 4), (2048, 60, 4), (64, 120, 2), (1024, 30, 8), (256, 250, 1), (4096, 40, 6)])
-def test_to_rns_from_rns_match_oracle(eng, oracle, n, bits, L):
+@pytest.mark.parametrize("n,bits,L", [(8192, 30, 4), (2048, 60, 4), (64, 120, 2), (1024, 30, 8), (256, 250, 1), (4096, 40, 6), (2048, 62, 3)])
+@pytest.mark.parametrize("word", [True, False])
+def test_to_rns_from_rns_match_oracle(eng, oracle, monkeypatch, n, bits, L, word):
+    """word = True: to_rns on the integer word classes runs the streaming kernel on the field type; False: the 256-bit container kernel."""
     import random as _r
+    if not word:
+        monkeypatch.setenv("FHE_HIP_NO_WORD_CONVERSIONS", "1")
     moduli = nm.ntt_primes(bits, n, L)
     Q = 1
     for q in moduli:
