@@ -899,10 +899,10 @@ static uint64_t inv_mod_u64(uint64_t a, uint64_t q) {       // a^(q-2) mod q, q 
     for (; e; e >>= 1) { if (e & 1) acc = acc * b % q; b = b * b % q; }
     return (uint64_t)acc;
 }
-template <class F>
+template <class F, class WT>
 static int to_rns_word(fhe_rns_ntt *h, void *d_rns, const void *d_values, uint32_t batch) {
     using E = typename F::E; using V = typename F::V16;
-    constexpr uint32_t NW = 32 / sizeof(E), W = 8 * sizeof(E);
+    constexpr uint32_t NW = 32 / sizeof(WT), W = 8 * sizeof(WT);
     if (!h->d_to_rns_w) {
         std::vector<E> ops((size_t)h->L * NW);
         for (uint32_t l = 0; l < h->L; l++) {
@@ -916,16 +916,17 @@ static int to_rns_word(fhe_rns_ntt *h, void *d_rns, const void *d_values, uint32
         int rc = upload(h, ops, &h->d_to_rns_w); if (rc) return rc;
     }
     const size_t halves = (size_t)batch * h->L * h->n * 2;
-    hipLaunchKernelGGL((fhe_dev::to_rns_word_kernel<F>), dim3(ew_grid(halves)), dim3(256), 0, h->stream, (V *)d_rns, (const V *)d_values,
+    hipLaunchKernelGGL((fhe_dev::to_rns_word_kernel<F, WT>), dim3(ew_grid(halves)), dim3(256), 0, h->stream, (V *)d_rns, (const V *)d_values,
                        (const fhe_dev::Limb<F> *)h->d_limbs, (const E *)h->d_to_rns_w, h->L, h->log_n, halves);
     return post_launch(h->stream, "to_rns_word_kernel");
 }
 extern "C" int fhe_rns_to_rns(fhe_rns_ntt_t *h, void *d_rns, const void *d_values, uint32_t batch) {
     int rc = check_call(h, batch, "to_rns"); if (rc) return rc;
     if (!d_rns || !d_values || d_rns == d_values) return fail(FHE_ERR_INVALID_ARG, "to_rns: null or aliased argument");
-    if (!getenv("FHE_HIP_NO_WORD_CONVERSIONS")) {       // integer word classes: a streaming kernel on the field type
-        if (h->width == FHE_WIDTH_32) return to_rns_word<fhe_dev::F32>(h, d_rns, d_values, batch);
-        if (h->width == FHE_WIDTH_64) return to_rns_word<fhe_dev::F64>(h, d_rns, d_values, batch);
+    if (!getenv("FHE_HIP_NO_WORD_CONVERSIONS")) {       // word-sized classes: a streaming kernel on the field type
+        if (h->width == FHE_WIDTH_32) return to_rns_word<fhe_dev::F32, uint32_t>(h, d_rns, d_values, batch);
+        if (h->width == FHE_WIDTH_52) return to_rns_word<fhe_dev::F52, uint32_t>(h, d_rns, d_values, batch);
+        if (h->width == FHE_WIDTH_64) return to_rns_word<fhe_dev::F64, uint64_t>(h, d_rns, d_values, batch);
     }
     if ((rc = ensure_crt(h))) return rc;
     const size_t count = (size_t)batch * h->n;
@@ -960,8 +961,9 @@ extern "C" int fhe_rns_from_rns(fhe_rns_ntt_t *h, void *d_values, const void *d_
     if (!d_rns || !d_values || d_rns == d_values) return fail(FHE_ERR_INVALID_ARG, "from_rns: null or aliased argument");
     if ((rc = ensure_crt(h))) return rc;
     if (h->crt_state < 0) return fail(FHE_ERR_UNSUPPORTED, "from_rns: the product of the moduli must be below 2^255 to fit a 256-bit container");
-    if (!getenv("FHE_HIP_NO_WORD_CONVERSIONS")) {       // integer word classes: word x 256-bit accumulation instead of 256-bit Montgomery products
+    if (!getenv("FHE_HIP_NO_WORD_CONVERSIONS")) {       // word-sized classes: word x 256-bit accumulation instead of 256-bit Montgomery products
         if (h->width == FHE_WIDTH_32) return from_rns_word<fhe_dev::F32>(h, d_values, d_rns, batch);
+        if (h->width == FHE_WIDTH_52) return from_rns_word<fhe_dev::F52>(h, d_values, d_rns, batch);
         if (h->width == FHE_WIDTH_64) return from_rns_word<fhe_dev::F64>(h, d_values, d_rns, batch);
     }
     const size_t count = (size_t)batch * h->n;

@@ -1314,16 +1314,17 @@ base_convert_word_kernel(typename F::V16 *__restrict__ out, const typename F::V1
     }
 }
 
-// rns[b][l][x] = values[b][x] mod q_l for ANY 256-bit value (RNS_NTTEngine::to_rns, include/ntt.cuh:114-115, declared only), integer
-// fields: the value is read as 256 / W words of W bits and reduced as sum_k word_k * (2^(W k) mod q_l); pow_ops[l * NW + k] is the
-// pw operand of 2^(W k) mod q_l, and a word needs no reduction of its own (operand < q, word < 2^W: the product is < q 2^W).
-template <class F>
+// rns[b][l][x] = values[b][x] mod q_l for ANY 256-bit value (RNS_NTTEngine::to_rns, include/ntt.cuh:114-115, declared only): the value is
+// read as 256 / W words of W bits and reduced as sum_k word_k * (2^(W k) mod q_l); pow_ops[l * NW + k] is the pw operand of
+// 2^(W k) mod q_l, and a word needs no reduction of its own (integer fields: operand < q, word < 2^W, product < q 2^W; FP64 field:
+// 32-bit words, far below its 2^48 operand bound).
+template <class F, class WT>     // WT: the word type the value is cut into (uint32_t for F32 and F52, uint64_t for F64)
 __global__ void __launch_bounds__(256)
 to_rns_word_kernel(typename F::V16 *__restrict__ rns, const typename F::V16 *__restrict__ values, const Limb<F> *__restrict__ limbs,
                    const typename F::E *__restrict__ pow_ops, uint32_t L, uint32_t log_n, size_t out_halves) {
     using E = typename F::E;
-    constexpr int NW = 32 / sizeof(E), HW = NW / 2;                    // words per container / per 16-byte half
-    typedef E VecE __attribute__((ext_vector_type(HW)));
+    constexpr int NW = 32 / sizeof(WT), HW = NW / 2;                   // words per container / per 16-byte half
+    typedef WT VecW __attribute__((ext_vector_type(HW)));
     const size_t stride = (size_t)gridDim.x * blockDim.x, n = (size_t)1 << log_n;
     for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < out_halves; g += stride) {
         E o = 0;
@@ -1331,20 +1332,20 @@ to_rns_word_kernel(typename F::V16 *__restrict__ rns, const typename F::V16 *__r
             const size_t c = g >> 1, x = c & (n - 1), pl = c >> log_n, b = pl / L;
             const uint32_t l = (uint32_t)(pl % L);
             const Limb<F> &P = limbs[l];
-            const VecE *v = reinterpret_cast<const VecE *>(values + ((b << log_n) + x) * 2);
-            const VecE lo = v[0], hi = v[1];
+            const VecW *v = reinterpret_cast<const VecW *>(values + ((b << log_n) + x) * 2);
+            const VecW lo = v[0], hi = v[1];
             const E *ops = pow_ops + (size_t)l * NW;
 #pragma unroll
             for (int k = 0; k < HW; k++) {
-                o = F::ew_add(o, mul_const<F>(ops[k], lo[k], P), P.q);
-                o = F::ew_add(o, mul_const<F>(ops[HW + k], hi[k], P), P.q);
+                o = F::ew_add(o, mul_const<F>(ops[k], (E)lo[k], P), P.q);
+                o = F::ew_add(o, mul_const<F>(ops[HW + k], (E)hi[k], P), P.q);
             }
         }
         __builtin_nontemporal_store(F::pack(o), rns + g);
     }
 }
 
-// values[b][x] = CRT of the L residues, in [0, Q)  (RNS_NTTEngine::from_rns, include/ntt.cuh:116-117, declared only), integer word
+// values[b][x] = CRT of the L residues, in [0, Q)  (RNS_NTTEngine::from_rns, include/ntt.cuh:116-117, declared only), word-sized
 // classes: sum_l [x_l * (Q/q_l)^-1]_{q_l} * (Q/q_l) is accumulated as word x 256-bit products in a 320-bit register array (the sum is
 // below L * Q) and brought into [0, Q) by at most L - 1 subtractions.  One lane per value; Mi[l] = Q / q_l as a plain integer.
 template <class F>
