@@ -247,6 +247,7 @@ struct fhe_rns_ntt {
     void *d_rescale_w = nullptr;         // word-sized classes: (q_last^-1 mod q_l) as pw operands, E[L-1] (owned by d_tables)
     void *d_bconv_w_minv = nullptr, *d_bconv_w_mat = nullptr;   // word-sized classes: base-conversion operands for bconv_w_target
     const void *bconv_w_target = nullptr;
+    std::vector<U256> bconv_moduli, bconv_w_moduli;   // the target bases the cached matrices were built for (a handle address can be re-used)
     void *d_from_rns_w_minv = nullptr, *d_from_rns_w_M = nullptr;   // integer word classes: CRT operands and Q / q_l (owned by d_tables)
     void *d_to_rns_w = nullptr;          // integer word classes: 2^(W k) mod q_l as pw operands, E[L][256 / W] (owned by d_tables)
     fhe_dev::CrtBig crt_big;
@@ -990,7 +991,7 @@ static int rescale_word(fhe_rns_ntt *h, void *d_out, const void *d_in, uint32_t 
 template <class F>
 static int base_convert_word(fhe_rns_ntt *h, fhe_rns_ntt *t, void *d_out, const void *d_in, uint32_t batch) {
     using E = typename F::E; using V = typename F::V16;
-    if (h->bconv_w_target != t) {
+    if (h->bconv_w_target != t || !(h->bconv_w_moduli == t->moduli)) {
         const uint32_t L = h->L, Lp = t->L;
         std::vector<E> minv(L), mat((size_t)L * Lp);
         for (uint32_t i = 0; i < L; i++) {
@@ -1007,7 +1008,7 @@ static int base_convert_word(fhe_rns_ntt *h, fhe_rns_ntt *t, void *d_out, const 
         }
         int rc;
         if ((rc = upload(h, minv, &h->d_bconv_w_minv)) || (rc = upload(h, mat, &h->d_bconv_w_mat))) return rc;   // earlier tables stay owned by d_tables
-        h->bconv_w_target = t;
+        h->bconv_w_target = t; h->bconv_w_moduli = t->moduli;
     }
     const size_t halves = (size_t)batch * t->L * h->n * 2;
     hipLaunchKernelGGL((fhe_dev::base_convert_word_kernel<F>), dim3(ew_grid(halves)), dim3(256), 0, h->stream, (V *)d_out, (const V *)d_in,
@@ -1054,7 +1055,7 @@ extern "C" int fhe_rns_fast_base_convert(fhe_rns_ntt_t *h, fhe_rns_ntt_t *target
         return base_convert_word<fhe_dev::F64>(h, target, d_out, d_in, batch);
     }
     if ((rc = ensure_crt(h)) || (rc = ensure_crt(target))) return rc;
-    if (h->bconv_target != target) {
+    if (h->bconv_target != target || !(h->bconv_moduli == target->moduli)) {
         std::vector<fhe_dev::u256> mat((size_t)h->L * target->L);
         for (uint32_t j = 0; j < target->L; j++) {
             fhe_host::Mod M(target->moduli[j]);
@@ -1065,7 +1066,7 @@ extern "C" int fhe_rns_fast_base_convert(fhe_rns_ntt_t *h, fhe_rns_ntt_t *target
             }
         }
         if ((rc = upload(h, mat, &h->d_bconv))) return rc;                    // earlier matrices stay owned by d_tables until destroy
-        h->bconv_target = target;
+        h->bconv_target = target; h->bconv_moduli = target->moduli;
     }
     const size_t count = (size_t)batch * h->n;
     hipLaunchKernelGGL(fhe_dev::fast_base_convert_kernel, dim3(ew_grid(count)), dim3(256), 0, h->stream, (fhe_dev::u256 *)d_out,

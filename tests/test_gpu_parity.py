@@ -1086,3 +1086,19 @@ def test_rns_base_without_a_ring(eng, oracle):
     narrow = eng.RnsNttEngine(8192, eng.find_ntt_primes(30, 8192, 2))
     with pytest.raises(eng.FheError):
         narrow.mul_mont_literal(dR, dRA, dRB, 1)                           # R = 2^256 products only exist on full-width handles
+
+
+def test_base_conversion_cache_survives_a_recycled_target_handle(eng, oracle):
+    """The conversion matrix is cached per target; a new target engine that happens to reuse a freed handle's address must not
+    see the old matrix."""
+    n = 2048
+    src = nm.ntt_primes(30, n, 3)
+    cands = [p for p in nm.ntt_primes(30, n, 12) if p not in src]
+    e = eng.RnsNttEngine(n, src); S = oracle.RnsPlan(n, src)
+    x = rns_poly(777, src, n, 1); dX = _up(eng, x); dY = eng.DeviceBuffer(2 * n * 32)
+    for k in range(4):                                           # create / convert / destroy: allocators hand the same block out again
+        dst = cands[2 * k:2 * k + 2]
+        t = eng.RnsNttEngine(n, dst)
+        e.fast_base_convert(t, dY, dX, 1)
+        assert np.array_equal(dY.download((1, 2, n, 4)), S.fast_base_convert(oracle.RnsPlan(n, dst), x))
+        del t
