@@ -983,9 +983,9 @@ static int rescale_word(fhe_rns_ntt *h, void *d_out, const void *d_in, uint32_t 
         for (uint32_t l = 0; l + 1 < h->L; l++) { const uint64_t q = h->moduli[l].w[0]; ops[l] = word_operand<F>(inv_mod_u64(ql % q, q), q); }
         int rc = upload(h, ops, &h->d_rescale_w); if (rc) return rc;
     }
-    const size_t halves = (size_t)batch * (h->L - 1) * h->n * 2;
-    hipLaunchKernelGGL((fhe_dev::rescale_word_kernel<F>), dim3(ew_grid(halves)), dim3(256), 0, h->stream, (V *)d_out, (const V *)d_in,
-                       (const fhe_dev::Limb<F> *)h->d_limbs, (const E *)h->d_rescale_w, h->L, h->log_n, halves);
+    const size_t count = (size_t)batch * h->n;
+    hipLaunchKernelGGL((fhe_dev::rescale_word_kernel<F>), dim3(ew_grid(count)), dim3(256), 0, h->stream, (V *)d_out, (const V *)d_in,
+                       (const fhe_dev::Limb<F> *)h->d_limbs, (const E *)h->d_rescale_w, h->L, h->log_n, count);
     return post_launch(h->stream, "rescale_word_kernel");
 }
 template <class F>

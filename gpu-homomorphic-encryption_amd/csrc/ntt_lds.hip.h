@@ -1258,37 +1258,35 @@ template <class F>
 __device__ __forceinline__ typename F::E mul_const(typename F::E cop, typename F::E x, const Limb<F> &P) {
     return F::canon_inv(F::pw_mul(cop, x, P.q, P.qinv), P.q);
 }
-// v < 2^63 (a canonical residue of another prime of the same class) reduced modulo q
-template <class F>
-__device__ __forceinline__ typename F::E reduce_into(typename F::E v, typename F::E q) {
-    if constexpr (sizeof(typename F::E) == 4) return v % q;           // 32-bit modulo instead of the 64-bit one of from_u64
-    else return F::from_u64((uint64_t)v, q);
-}
 // out[b][l][x] = (in[b][l][x] - [c]_{q_l}) * q_last^-1 mod q_l, c = the CENTRED residue of in[b][L-1][x] modulo q_last
-// (RNSContext::mod_switch_rns, include/rns.cuh:44, declared only).  One 16-byte half container of the output per lane.
+// (RNSContext::mod_switch_rns, include/rns.cuh:44, declared only).  (x_l - c) * inv = x_l * inv - c * inv with c = +-mag, mag < q_last:
+// a residue of ANOTHER prime of the class is a valid second operand of the constant product as it stands (no division to reduce it).
+// One lane per (b, x): the last limb is loaded once and every remaining limb produced from it, full 32-byte containers stored as two
+// 16-byte halves by the same lane (+22 % at N = 8192 over one lane per output half-container, which re-read the last limb per limb).
 template <class F>
 __global__ void __launch_bounds__(256)
 rescale_word_kernel(typename F::V16 *__restrict__ out, const typename F::V16 *__restrict__ in, const Limb<F> *__restrict__ limbs,
-                    const typename F::E *__restrict__ inv_ops, uint32_t L, uint32_t log_n, size_t out_halves) {
+                            const typename F::E *__restrict__ inv_ops, uint32_t L, uint32_t log_n, size_t count /* batch * n */) {
     using E = typename F::E;
     const size_t stride = (size_t)gridDim.x * blockDim.x, n = (size_t)1 << log_n;
-    const E q_last = limbs[L - 1].q, half = (E)(((uint64_t)q_last - 1) >> 1);              // floor(q_last / 2), q_last odd
-    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < out_halves; g += stride) {
-        E o = 0;
-        if (!(g & 1)) {
-            const size_t c = g >> 1, x = c & (n - 1), pl = c >> log_n, b = pl / (L - 1);
-            const uint32_t l = (uint32_t)(pl % (L - 1));
+    const E q_last = limbs[L - 1].q, half = (E)(((uint64_t)q_last - 1) >> 1);
+    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < count; g += stride) {
+        const size_t b = g >> log_n, x = g & (n - 1);
+        const E cl = F::load_low(in + (((b * L + (L - 1)) << log_n) + x) * 2);
+        const bool neg = cl > half;
+        const E mag = neg ? q_last - cl : cl;
+        for (uint32_t l = 0; l + 1 < L; l++) {
             const Limb<F> &P = limbs[l];
-            const E cl = F::load_low(in + (((b * L + (L - 1)) << log_n) + x) * 2);
             const E xl = F::load_low(in + (((b * L + l) << log_n) + x) * 2);
-            const bool neg = cl > half;
-            const E m = reduce_into<F>(neg ? q_last - cl : cl, P.q);
-            const E r = (neg && m != (E)0) ? P.q - m : m;
-            o = mul_const<F>(inv_ops[l], F::ew_sub(xl, r, P.q), P);
+            const E a = mul_const<F>(inv_ops[l], xl, P), m = mul_const<F>(inv_ops[l], mag, P);
+            const E o = neg ? F::ew_add(a, m, P.q) : F::ew_sub(a, m, P.q);
+            typename F::V16 *dst = out + (((b * (L - 1) + l) << log_n) + x) * 2;
+            __builtin_nontemporal_store(F::pack(o), dst);
+            __builtin_nontemporal_store(F::pack((E)0), dst + 1);
         }
-        __builtin_nontemporal_store(F::pack(o), out + g);
     }
 }
+
 // out[b][j][x] = sum_i ([x_i * (Q/q_i)^-1]_{q_i} mod p_j) * ((Q/q_i) mod p_j) mod p_j   (RNSContext::base_extend, include/rns.cuh:47-48, declared only).
 // minv_ops[i] is an operand of source limb i, mat_ops[i * Lp + j] an operand of target limb j.  One half container of the output per lane.
 template <class F>
@@ -1307,7 +1305,7 @@ base_convert_word_kernel(typename F::V16 *__restrict__ out, const typename F::V1
             for (uint32_t i = 0; i < L; i++) {
                 const Limb<F> &S = src[i];
                 const E ti = mul_const<F>(minv_ops[i], F::load_low(in + (((b * L + i) << log_n) + x) * 2), S);
-                o = F::ew_add(o, mul_const<F>(mat_ops[(size_t)i * Lp + j], reduce_into<F>(ti, D.q), D), D.q);
+                o = F::ew_add(o, mul_const<F>(mat_ops[(size_t)i * Lp + j], ti, D), D.q);   // t_i < q_i: a valid operand modulo p_j as it stands
             }
         }
         __builtin_nontemporal_store(F::pack(o), out + g);
