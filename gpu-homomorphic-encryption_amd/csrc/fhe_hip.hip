@@ -507,6 +507,8 @@ static int lds_run(fhe_rns_ntt *h, int op, void *r0, void *r1, void *r2, const v
     if (!fn) return fail(FHE_ERR_UNSUPPORTED, "transform size outside the LDS-resident range");
     fhe_dev::LdsArgs A{op, r0, r1, r2, a0, a1, b0, b1, h->d_limbs, h->L, polys, h->stream};
     A.single_transforms = getenv("FHE_HIP_NO_PAIRED_TRANSFORMS") != nullptr;
+    A.square = !getenv("FHE_HIP_NO_SQUARE_KERNELS") &&
+               ((op == fhe_dev::LDS_MULTIPLY && a0 == b0) || (op == fhe_dev::LDS_CT_MULTIPLY && a0 == b0 && a1 == b1));
     fn(A);
     return post_launch(h->stream, what);
 }

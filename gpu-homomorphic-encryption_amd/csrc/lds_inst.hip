@@ -22,14 +22,23 @@ void CAT(lds_launch_, FHE_FIELD, FHE_LOGN)(const LdsArgs &A) {
             hipLaunchKernelGGL((ntt_inverse_kernel<F, LOGN>), grid, block, 0, A.stream, (char *)A.r0, limbs, A.L);
             break;
         case LDS_MULTIPLY:
-            hipLaunchKernelGGL((ntt_multiply_kernel<F, LOGN, MULT_MINW>), grid, block, 0, A.stream, (char *)A.r0, (const char *)A.a0,
-                               (const char *)A.b0, limbs, A.L);
+            if (A.square)
+                hipLaunchKernelGGL((ntt_multiply_kernel<F, LOGN, MULT_MINW, true>), grid, block, 0, A.stream, (char *)A.r0, (const char *)A.a0,
+                                   (const char *)A.b0, limbs, A.L);
+            else
+                hipLaunchKernelGGL((ntt_multiply_kernel<F, LOGN, MULT_MINW>), grid, block, 0, A.stream, (char *)A.r0, (const char *)A.a0,
+                                   (const char *)A.b0, limbs, A.L);
             break;
         case LDS_CT_MULTIPLY:
             if constexpr (lds_ct_fused(sizeof(typename F::E), LOGN)) {
-                hipLaunchKernelGGL((ntt_ct_multiply_kernel<F, LOGN>), grid, block, 0, A.stream, (char *)A.r0, (char *)A.r1,
-                                   (char *)A.r2, (const char *)A.a0, (const char *)A.a1, (const char *)A.b0, (const char *)A.b1,
-                                   limbs, A.L);
+                if (A.square)
+                    hipLaunchKernelGGL((ntt_ct_multiply_kernel<F, LOGN, true>), grid, block, 0, A.stream, (char *)A.r0, (char *)A.r1,
+                                       (char *)A.r2, (const char *)A.a0, (const char *)A.a1, (const char *)A.b0, (const char *)A.b1,
+                                       limbs, A.L);
+                else
+                    hipLaunchKernelGGL((ntt_ct_multiply_kernel<F, LOGN>), grid, block, 0, A.stream, (char *)A.r0, (char *)A.r1,
+                                       (char *)A.r2, (const char *)A.a0, (const char *)A.a1, (const char *)A.b0, (const char *)A.b1,
+                                       limbs, A.L);
             } else {   // four transformed operands exceed the register file: c0, c2 by the fused multiply, c1 by the two-product kernel
                 hipLaunchKernelGGL((ntt_multiply_kernel<F, LOGN, MULT_MINW>), grid, block, 0, A.stream, (char *)A.r0,
                                    (const char *)A.a0, (const char *)A.b0, limbs, A.L);

@@ -601,7 +601,8 @@ ntt_inverse_kernel(char *__restrict__ data, const Limb<F> *__restrict__ limbs, u
 }
 
 // NTTEngine::multiply in one launch: r = INTT(NTT(a) .* NTT(b)); HBM traffic = read a + read b + write r.
-template <class F, int LOGN, int MINW = 1>
+// SQUARE: b is a (the host passes the flag when the operand pointers are equal): one load, one forward transform, 2*S of traffic.
+template <class F, int LOGN, int MINW = 1, bool SQUARE = false>
 __global__ void __launch_bounds__(NttCfg<LOGN>::T, MINW)
 ntt_multiply_kernel(char *res, const char *a, const char *b,      // no __restrict__: res may alias a and / or b (in-place product)
                     const Limb<F> *__restrict__ limbs, uint32_t L) {
@@ -611,16 +612,23 @@ ntt_multiply_kernel(char *res, const char *a, const char *b,      // no __restri
     const uint32_t tid = threadIdx.x, p = blockIdx.x;
     const Limb<F> P = limbs[p % L];
     const size_t off = (size_t)p * (C::N * 32);
-    E x[32], y[32];
+    E x[32];
     load_A<F, LOGN>(a + off, tid, x);
-    load_A<F, LOGN>(b + off, tid, y);      // issued before a's butterflies: b's HBM latency hides under them
-    fwd_core<F, LOGN>(x, lds, tid, P);
+    if constexpr (SQUARE) {
+        fwd_core<F, LOGN>(x, lds, tid, P);
 #pragma unroll
-    for (int r = 0; r < 32; r++) x[r] = F::canon_fwd(x[r], P.q, P.q2, P.qinv);   // canonical: keeps x*y < q*2^W
-    __syncthreads();                       // all Z-pattern reads of a are done before b overwrites the slots
-    fwd_core<F, LOGN>(y, lds, tid, P);
+        for (int r = 0; r < 32; r++) { const E c = F::canon_fwd(x[r], P.q, P.q2, P.qinv); x[r] = F::pw_mul(c, c, P.q, P.qinv); }
+    } else {
+        E y[32];
+        load_A<F, LOGN>(b + off, tid, y);  // issued before a's butterflies: b's HBM latency hides under them
+        fwd_core<F, LOGN>(x, lds, tid, P);
 #pragma unroll
-    for (int r = 0; r < 32; r++) x[r] = F::pw_mul(x[r], y[r], P.q, P.qinv);   // [0,2q), carries 2^-W
+        for (int r = 0; r < 32; r++) x[r] = F::canon_fwd(x[r], P.q, P.q2, P.qinv);   // canonical: keeps x*y < q*2^W
+        __syncthreads();                   // all Z-pattern reads of a are done before b overwrites the slots
+        fwd_core<F, LOGN>(y, lds, tid, P);
+#pragma unroll
+        for (int r = 0; r < 32; r++) x[r] = F::pw_mul(x[r], y[r], P.q, P.qinv);   // [0,2q), carries 2^-W
+    }
     inv_core<F, LOGN>(x, lds, tid, P, P.ninv_r, P.ninv_r_s, P.ninvw_r, P.ninvw_r_s);
 #pragma unroll
     for (int r = 0; r < 32; r++) x[r] = F::canon_inv(x[r], P.q);
@@ -672,7 +680,9 @@ ntt_mac2_kernel(char *__restrict__ res, const char *__restrict__ a0, const char 
 
 // FHEContext::multiply tensor product in one launch (src/fhe.cu:199-218): 4 forward + 3 inverse transforms,
 // HBM traffic = read 4 polynomials + write 3.
-template <class F, int LOGN>
+// SQUARE: (b0, b1) is (a0, a1) (the host passes the flag when the operand pointers are equal -- squaring a ciphertext): two loads and
+// two forward transforms instead of four, c1 = 2 a0 a1; 5*S of traffic instead of 7*S.
+template <class F, int LOGN, bool SQUARE = false>
 __global__ void __launch_bounds__(NttCfg<LOGN>::T)
 ntt_ct_multiply_kernel(char *__restrict__ c0, char *__restrict__ c1, char *__restrict__ c2,
                        const char *__restrict__ a0, const char *__restrict__ a1,
@@ -684,25 +694,38 @@ ntt_ct_multiply_kernel(char *__restrict__ c0, char *__restrict__ c1, char *__res
     const uint32_t tid = threadIdx.x, p = blockIdx.x;
     const Limb<F> P = limbs[p % L];
     const size_t off = (size_t)p * (C::N * 32);
-    E A0[32], A1[32], B0[32], B1[32];
+    E A0[32], A1[32], B0[32];
     load_A<F, LOGN>(a0 + off, tid, A0);
     load_A<F, LOGN>(a1 + off, tid, A1);
     fwd_core<F, LOGN>(A0, lds, tid, P);
-    load_A<F, LOGN>(b0 + off, tid, B0);
-    __syncthreads();
-    fwd_core<F, LOGN>(A1, lds, tid, P);
-    load_A<F, LOGN>(b1 + off, tid, B1);
-    __syncthreads();
-    fwd_core<F, LOGN>(B0, lds, tid, P);
-    __syncthreads();
-    fwd_core<F, LOGN>(B1, lds, tid, P);
+    if constexpr (SQUARE) {
+        __syncthreads();
+        fwd_core<F, LOGN>(A1, lds, tid, P);
 #pragma unroll
-    for (int r = 0; r < 32; r++) {
-        E u0 = F::canon_fwd(A0[r], P.q, P.q2, P.qinv), u1 = F::canon_fwd(A1[r], P.q, P.q2, P.qinv);   // canonical a-side
-        E v0 = B0[r], v1 = B1[r];                                                             // lazy b-side (< 4q)
-        A0[r] = F::pw_mul(u0, v0, P.q, P.qinv);                  // [0,2q)
-        A1[r] = F::pw_mul2(u0, v1, u1, v0, P.q, P.q2, P.qinv);   // a0*b1 + a1*b0 with one shared reduction on the 32-bit field
-        B0[r] = F::pw_mul(u1, v1, P.q, P.qinv);
+        for (int r = 0; r < 32; r++) {
+            const E u0 = F::canon_fwd(A0[r], P.q, P.q2, P.qinv), u1 = F::canon_fwd(A1[r], P.q, P.q2, P.qinv);
+            A0[r] = F::pw_mul(u0, u0, P.q, P.qinv);
+            A1[r] = F::pw_mul2(u0, u1, u1, u0, P.q, P.q2, P.qinv);   // 2 a0 a1
+            B0[r] = F::pw_mul(u1, u1, P.q, P.qinv);
+        }
+    } else {
+        E B1[32];
+        load_A<F, LOGN>(b0 + off, tid, B0);
+        __syncthreads();
+        fwd_core<F, LOGN>(A1, lds, tid, P);
+        load_A<F, LOGN>(b1 + off, tid, B1);
+        __syncthreads();
+        fwd_core<F, LOGN>(B0, lds, tid, P);
+        __syncthreads();
+        fwd_core<F, LOGN>(B1, lds, tid, P);
+#pragma unroll
+        for (int r = 0; r < 32; r++) {
+            E u0 = F::canon_fwd(A0[r], P.q, P.q2, P.qinv), u1 = F::canon_fwd(A1[r], P.q, P.q2, P.qinv);   // canonical a-side
+            E v0 = B0[r], v1 = B1[r];                                                             // lazy b-side (< 4q)
+            A0[r] = F::pw_mul(u0, v0, P.q, P.qinv);                  // [0,2q)
+            A1[r] = F::pw_mul2(u0, v1, u1, v0, P.q, P.q2, P.qinv);   // a0*b1 + a1*b0 with one shared reduction on the 32-bit field
+            B0[r] = F::pw_mul(u1, v1, P.q, P.qinv);
+        }
     }
     inv_core<F, LOGN>(A0, lds, tid, P, P.ninv_r, P.ninv_r_s, P.ninvw_r, P.ninvw_r_s);
 #pragma unroll

@@ -138,7 +138,8 @@ int fhe_ntt_inverse(fhe_ntt_t *h, void *d_data, uint32_t batch);
 /* ntt_pointwise_mul_kernel's intent (kernels/ntt_kernels.cu:124-137): r = a .* b mod q, plain product. */
 int fhe_ntt_pointwise(fhe_ntt_t *h, void *d_r, const void *d_a, const void *d_b, uint32_t batch);
 /* NTTEngine::multiply (src/ntt.cu:49-75): r = a (*) b mod (x^n + 1, q); d_a, d_b are not modified unless d_r aliases
- * one of them, which is allowed (in-place product, squaring with d_a == d_b).  One fused launch on the word-sized paths. */
+ * one of them, which is allowed (in-place product, squaring with d_a == d_b).  One fused launch on the word-sized paths; with
+ * d_a == d_b the squaring form of the kernel runs (one load, one forward transform: 2*S bytes of traffic instead of 3*S). */
 int fhe_ntt_multiply(fhe_ntt_t *h, void *d_r, const void *d_a, const void *d_b, uint32_t batch);
 
 /* ---- RNS engine: fhe::RNS_NTTEngine ---------------------------------------------------------- */

@@ -1,0 +1,27 @@
+#!/usr/bin/env python3
+"""Squaring forms of the fused multiply and the tensor product (operand pointers equal) against the general forms."""
+import importlib
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+pkg = importlib.import_module("gpu-homomorphic-encryption_amd")
+from workload import rns_poly
+n, L, B = 8192, 4, 2048
+moduli = pkg.find_ntt_primes(30, n, L); eng = pkg.RnsNttEngine(n, moduli)
+S = 32 * n * L
+bufs = [pkg.DeviceBuffer(B * S) for _ in range(5)]
+x = rns_poly(1, moduli, n, 64)
+for b in bufs[:2]:
+    for i in range(0, B, 64):
+        pkg.lib().fhe_hip_memcpy_h2d(b.ptr + i * S, x.ctypes.data, x.nbytes)
+def timed(fn, name, bytes_):
+    fn(); pkg.capi.sync(); t = pkg.Timer(); t.start(eng)
+    for _ in range(10): fn()
+    t.stop(eng); pkg.capi.sync(); ms = t.elapsed_ms() / 10
+    print(f"{name:28s} {ms:7.3f} ms {B / ms * 1e3:12.0f} /s  {bytes_ / ms / 1e6:8.1f} GB/s")
+timed(lambda: eng.multiply(bufs[2], bufs[0], bufs[1], B), "multiply(a, b)", 3 * S * B)
+timed(lambda: eng.multiply(bufs[2], bufs[0], bufs[0], B), "multiply(a, a)  [square]", 2 * S * B)
+timed(lambda: eng.ct_multiply(bufs[2], bufs[3], bufs[4], bufs[0], bufs[1], bufs[1], bufs[0], B), "ct_multiply(a, b)", 7 * S * B)
+timed(lambda: eng.ct_multiply(bufs[2], bufs[3], bufs[4], bufs[0], bufs[1], bufs[0], bufs[1], B), "ct_multiply(a, a) [square]", 5 * S * B)

@@ -1102,3 +1102,28 @@ def test_base_conversion_cache_survives_a_recycled_target_handle(eng, oracle):
         e.fast_base_convert(t, dY, dX, 1)
         assert np.array_equal(dY.download((1, 2, n, 4)), S.fast_base_convert(oracle.RnsPlan(n, dst), x))
         del t
+
+
+@pytest.mark.parametrize("n,spec,batch", [(8192, ("bits", 30, 4), 5), (4096, ("bits", 40, 2), 3), (2048, ("bits", 60, 2), 2), (16384, ("bits", 30, 2), 2),
+                                          (16384, ("bits", 40, 2), 1), (256, ("bits", 250, 1), 2)])
+@pytest.mark.parametrize("square_kernels", [True, False])
+def test_squaring_forms_match_oracle(eng, oracle, monkeypatch, n, spec, batch, square_kernels):
+    """multiply(a, a) and ct_multiply((a0, a1), (a0, a1)) take the squaring forms of the kernels (one load and one forward transform per
+    operand) when the operand pointers are equal; same bits as the oracle's general product and as the general kernels."""
+    if not square_kernels:
+        monkeypatch.setenv("FHE_HIP_NO_SQUARE_KERNELS", "1")
+    moduli = _moduli(spec, n)
+    e = eng.RnsNttEngine(n, moduli); rp = oracle.RnsPlan(n, moduli)
+    a0, a1 = rns_poly(1201, moduli, n, batch), rns_poly(1202, moduli, n, batch)
+    dA0, dA1 = _up(eng, a0), _up(eng, a1)
+    dR = eng.DeviceBuffer(a0.nbytes)
+    e.multiply(dR, dA0, dA0, batch)
+    assert np.array_equal(dR.download(a0.shape), rp.polymul(a0, a0, threads=8))
+    dC = [eng.DeviceBuffer(a0.nbytes) for _ in range(3)]
+    e.ct_multiply(dC[0], dC[1], dC[2], dA0, dA1, dA0, dA1, batch)
+    want = rp.ct_multiply(a0, a1, a0, a1, threads=8)
+    for d, w in zip(dC, want):
+        assert np.array_equal(d.download(a0.shape), w)
+    assert np.array_equal(dA0.download(a0.shape), a0) and np.array_equal(dA1.download(a0.shape), a1)      # operands preserved
+    e.multiply(dA0, dA0, dA0, batch)                                                                         # in-place square
+    assert np.array_equal(dA0.download(a0.shape), rp.polymul(a0, a0, threads=8))
