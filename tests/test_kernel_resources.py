@@ -38,23 +38,24 @@ def resources(tmp_path_factory):
     return kernels
 
 
-def _one(kernels, needle):
+def _all(kernels, needle, expect):
+    """Every instantiated variant of a kernel (e.g. the general and the squaring form)."""
     hits = [v for k, v in kernels.items() if needle in k]
-    assert len(hits) == 1, (needle, [k for k in kernels if needle in k])
-    return hits[0]
+    assert len(hits) == expect, (needle, [k for k in kernels if needle in k])
+    return hits
 
 
 def test_streaming_kernels_keep_four_workgroups_per_cu(resources):
-    for name in ("ntt_multiply_kernel", "ntt_forward_kernel", "ntt_inverse_kernel"):
-        k = _one(resources, name)
-        assert k["spill"] == 0 and k.get("scratch", 0) == 0, (name, k)
-        assert k["vgprs"] <= 128 and k["occupancy"] >= 4, (name, k)        # 4 waves per SIMD = 4 workgroups of 256 threads per CU
-        assert k["lds"] == 33792, (name, k)                                 # (8192 + 8192 / 32) * 4 bytes: 4 x 33 KiB <= 160 KiB
+    for name, variants in (("ntt_multiply_kernel", 2), ("ntt_forward_kernel", 1), ("ntt_inverse_kernel", 1)):
+        for k in _all(resources, name, variants):
+            assert k["spill"] == 0 and k.get("scratch", 0) == 0, (name, k)
+            assert k["vgprs"] <= 128 and k["occupancy"] >= 4, (name, k)    # 4 waves per SIMD = 4 workgroups of 256 threads per CU
+            assert k["lds"] == 33792, (name, k)                             # (8192 + 8192 / 32) * 4 bytes: 4 x 33 KiB <= 160 KiB
 
 
 def test_compute_bound_kernels_do_not_spill(resources):
-    for name, lds in (("ntt_ct_multiply_kernel", 33792), ("ntt_keyswitch2_kernel", 2 * 33792), ("ntt_extprod2_kernel", 2 * 33792)):
-        k = _one(resources, name)
-        assert k["spill"] == 0 and k.get("scratch", 0) == 0, (name, k)
-        assert k["vgprs"] <= 256 and k["occupancy"] >= 2, (name, k)        # 2 waves per SIMD = 2 workgroups per CU
-        assert k["lds"] == lds, (name, k)                                   # 2 x 66 KiB <= 160 KiB
+    for name, variants, lds in (("ntt_ct_multiply_kernel", 2, 33792), ("ntt_keyswitch2_kernel", 1, 2 * 33792), ("ntt_extprod2_kernel", 1, 2 * 33792)):
+        for k in _all(resources, name, variants):
+            assert k["spill"] == 0 and k.get("scratch", 0) == 0, (name, k)
+            assert k["vgprs"] <= 256 and k["occupancy"] >= 2, (name, k)    # 2 waves per SIMD = 2 workgroups per CU
+            assert k["lds"] == lds, (name, k)                               # 2 x 66 KiB <= 160 KiB
