@@ -80,6 +80,7 @@ def lib():
         "fhe_blind_rotate": ([vp, P(vp), P(vp), u32, vp, vp, vp, vp, vp, u32], ci),
         "fhe_rns_fast_base_convert": ([vp, vp, vp, vp, u32], ci),
         "fhe_rns_base_create": ([P(vp), vp, u32], ci),
+        "fhe_rns_ntt_multiply_bcast": ([vp, vp, vp, vp, u32], ci),
         "fhe_rns_mul_mont_literal": ([vp, vp, vp, vp, u32], ci),
         "fhe_ref_forward_kernel_literal": ([vp, vp, U64x4, u64, u32, u32, vp], ci),
         "fhe_ref_inverse_kernel_literal": ([vp, vp, U64x4, u64, U64x4, u32, u32, vp], ci),
@@ -331,6 +332,9 @@ class RnsNttEngine:
 
     def multiply(self, d_r, d_a, d_b, batch=1):
         _check(lib().fhe_rns_ntt_multiply(self.h, _ptr(d_r), _ptr(d_a), _ptr(d_b), batch))
+
+    def multiply_bcast(self, d_r, d_a, d_b_one, batch=1):
+        _check(lib().fhe_rns_ntt_multiply_bcast(self.h, _ptr(d_r), _ptr(d_a), _ptr(d_b_one), batch))
 
     def poly_add(self, d_r, d_a, d_b, batch=1):
         _check(lib().fhe_rns_poly_add(self.h, _ptr(d_r), _ptr(d_a), _ptr(d_b), batch))

@@ -502,12 +502,13 @@ static int run256_ew(fhe_rns_ntt *h, void *r, const void *a, const void *b, uint
 
 // ---- LDS-resident path launchers (kernels live in lds_inst.hip, one object per (field, log2 n)) ---------
 static int lds_run(fhe_rns_ntt *h, int op, void *r0, void *r1, void *r2, const void *a0, const void *a1, const void *b0,
-                   const void *b1, uint32_t polys, const char *what) {
+                   const void *b1, uint32_t polys, const char *what, uint32_t b_polys = 0) {
     fhe_dev::lds_launch_fn fn = fhe_dev::lds_lookup(h->width == FHE_WIDTH_32 ? 32 : h->width == FHE_WIDTH_52 ? 52 : 64, (int)h->log_n);
     if (!fn) return fail(FHE_ERR_UNSUPPORTED, "transform size outside the LDS-resident range");
     fhe_dev::LdsArgs A{op, r0, r1, r2, a0, a1, b0, b1, h->d_limbs, h->L, polys, h->stream};
     A.single_transforms = getenv("FHE_HIP_NO_PAIRED_TRANSFORMS") != nullptr;
-    A.square = !getenv("FHE_HIP_NO_SQUARE_KERNELS") &&
+    A.b_polys = b_polys;
+    A.square = !b_polys && !getenv("FHE_HIP_NO_SQUARE_KERNELS") &&
                ((op == fhe_dev::LDS_MULTIPLY && a0 == b0) || (op == fhe_dev::LDS_CT_MULTIPLY && a0 == b0 && a1 == b1));
     fn(A);
     return post_launch(h->stream, what);
@@ -623,6 +624,17 @@ extern "C" int fhe_rns_ntt_multiply(fhe_rns_ntt_t *h, void *r, const void *a, co
     int rc = check_call(h, batch, "multiply"); if (rc) return rc;
     if (!r || !a || !b) return fail(FHE_ERR_INVALID_ARG, "multiply: null argument");
     return do_multiply(h, r, a, b, batch);
+}
+extern "C" int fhe_rns_ntt_multiply_bcast(fhe_rns_ntt_t *h, void *r, const void *a, const void *b_one, uint32_t batch) {
+    int rc = check_call(h, batch, "multiply_bcast"); if (rc) return rc;
+    if (!r || !a || !b_one) return fail(FHE_ERR_INVALID_ARG, "multiply_bcast: null argument");
+    if (r == b_one) return fail(FHE_ERR_INVALID_ARG, "multiply_bcast: the result must not overwrite the shared operand");
+    if (h->width != FHE_WIDTH_256)   // every workgroup reads limb (p % L) of the one shared polynomial: L2 hits after the first use
+        return lds_run(h, fhe_dev::LDS_MULTIPLY, r, nullptr, nullptr, a, nullptr, b_one, nullptr, batch * h->L, "ntt_multiply_kernel", h->L);
+    const size_t S = (size_t)h->L * h->n * 32;
+    for (uint32_t i = 0; i < batch; i++)
+        if ((rc = do_multiply(h, (char *)r + i * S, (const char *)a + i * S, b_one, 1))) return rc;
+    return FHE_OK;
 }
 extern "C" int fhe_rns_poly_add(fhe_rns_ntt_t *h, void *r, const void *a, const void *b, uint32_t batch) {
     int rc = check_call(h, batch, "poly_add"); if (rc) return rc;

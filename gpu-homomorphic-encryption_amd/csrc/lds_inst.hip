@@ -24,10 +24,10 @@ void CAT(lds_launch_, FHE_FIELD, FHE_LOGN)(const LdsArgs &A) {
         case LDS_MULTIPLY:
             if (A.square)
                 hipLaunchKernelGGL((ntt_multiply_kernel<F, LOGN, MULT_MINW, true>), grid, block, 0, A.stream, (char *)A.r0, (const char *)A.a0,
-                                   (const char *)A.b0, limbs, A.L);
+                                   (const char *)A.b0, limbs, A.L, 0u);
             else
                 hipLaunchKernelGGL((ntt_multiply_kernel<F, LOGN, MULT_MINW>), grid, block, 0, A.stream, (char *)A.r0, (const char *)A.a0,
-                                   (const char *)A.b0, limbs, A.L);
+                                   (const char *)A.b0, limbs, A.L, A.b_polys ? 1u : 0u);
             break;
         case LDS_CT_MULTIPLY:
             if constexpr (lds_ct_fused(sizeof(typename F::E), LOGN)) {
@@ -41,9 +41,9 @@ void CAT(lds_launch_, FHE_FIELD, FHE_LOGN)(const LdsArgs &A) {
                                        limbs, A.L);
             } else {   // four transformed operands exceed the register file: c0, c2 by the fused multiply, c1 by the two-product kernel
                 hipLaunchKernelGGL((ntt_multiply_kernel<F, LOGN, MULT_MINW>), grid, block, 0, A.stream, (char *)A.r0,
-                                   (const char *)A.a0, (const char *)A.b0, limbs, A.L);
+                                   (const char *)A.a0, (const char *)A.b0, limbs, A.L, 0u);
                 hipLaunchKernelGGL((ntt_multiply_kernel<F, LOGN, MULT_MINW>), grid, block, 0, A.stream, (char *)A.r2,
-                                   (const char *)A.a1, (const char *)A.b1, limbs, A.L);
+                                   (const char *)A.a1, (const char *)A.b1, limbs, A.L, 0u);
                 hipLaunchKernelGGL((ntt_mac2_kernel<F, LOGN, MULT_MINW>), grid, block, 0, A.stream, (char *)A.r1, (const char *)A.a0,
                                    (const char *)A.b1, (const char *)A.a1, (const char *)A.b0, limbs, A.L);
             }

@@ -43,6 +43,7 @@ struct LdsArgs {
     const uint32_t *shifts = nullptr;
     bool global_twiddles = false;        // testing aid (FHE_HIP_NO_LDS_TWIDDLES=1): run the variant that reads twiddles from L2
     bool single_transforms = false;      // testing aid (FHE_HIP_NO_PAIRED_TRANSFORMS=1): one digit transform at a time
+    uint32_t b_polys = 0;                // LDS_MULTIPLY: polynomials behind b0 (0 = as many as the batch; L = one RNS polynomial broadcast over the batch)
     bool square = false;                 // LDS_MULTIPLY: b0 == a0; LDS_CT_MULTIPLY: (b0, b1) == (a0, a1) -- the squaring forms of the kernels
 };
 

@@ -602,15 +602,18 @@ ntt_inverse_kernel(char *__restrict__ data, const Limb<F> *__restrict__ limbs, u
 
 // NTTEngine::multiply in one launch: r = INTT(NTT(a) .* NTT(b)); HBM traffic = read a + read b + write r.
 // SQUARE: b is a (the host passes the flag when the operand pointers are equal): one load, one forward transform, 2*S of traffic.
+// bcast != 0: b holds ONE RNS polynomial ([L][n]) that is multiplied into every element of the batch (served from L2 after its first
+// use: 2*S of HBM traffic per product).
 template <class F, int LOGN, int MINW = 1, bool SQUARE = false>
 __global__ void __launch_bounds__(NttCfg<LOGN>::T, MINW)
 ntt_multiply_kernel(char *res, const char *a, const char *b,      // no __restrict__: res may alias a and / or b (in-place product)
-                    const Limb<F> *__restrict__ limbs, uint32_t L) {
+                    const Limb<F> *__restrict__ limbs, uint32_t L, uint32_t bcast) {
     using C = NttCfg<LOGN>;
     using E = typename F::E;
     __shared__ E lds[C::LDS_ELEMS];
     const uint32_t tid = threadIdx.x, p = blockIdx.x;
-    const Limb<F> P = limbs[p % L];
+    const uint32_t limb = p % L;
+    const Limb<F> P = limbs[limb];
     const size_t off = (size_t)p * (C::N * 32);
     E x[32];
     load_A<F, LOGN>(a + off, tid, x);
@@ -620,7 +623,7 @@ ntt_multiply_kernel(char *res, const char *a, const char *b,      // no __restri
         for (int r = 0; r < 32; r++) { const E c = F::canon_fwd(x[r], P.q, P.q2, P.qinv); x[r] = F::pw_mul(c, c, P.q, P.qinv); }
     } else {
         E y[32];
-        load_A<F, LOGN>(b + off, tid, y);  // issued before a's butterflies: b's HBM latency hides under them
+        load_A<F, LOGN>(b + (size_t)(bcast ? limb : p) * (C::N * 32), tid, y);   // issued before a's butterflies: b's HBM latency hides under them
         fwd_core<F, LOGN>(x, lds, tid, P);
 #pragma unroll
         for (int r = 0; r < 32; r++) x[r] = F::canon_fwd(x[r], P.q, P.q2, P.qinv);   // canonical: keeps x*y < q*2^W

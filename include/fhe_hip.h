@@ -160,6 +160,10 @@ int fhe_rns_ntt_inverse(fhe_rns_ntt_t *h, void *d_data, uint32_t batch);
 int fhe_rns_ntt_pointwise(fhe_rns_ntt_t *h, void *d_r, const void *d_a, const void *d_b, uint32_t batch);
 /* multiply_rns (include/ntt.cuh:124-126; declared, never defined in the reference). */
 int fhe_rns_ntt_multiply(fhe_rns_ntt_t *h, void *d_r, const void *d_a, const void *d_b, uint32_t batch);
+/* The same product with ONE polynomial d_b_one ([L][n]) multiplied into every element of a batch d_a ([batch][L][n]) -- what
+ * FHEContext does with a key or a plaintext (pk0 * u, c_i * pt: src/fhe.cu:160-166, include/fhe.cuh:104).  The shared operand is served
+ * from L2 after its first use: 2*S bytes of HBM traffic per product instead of 3*S.  d_r may alias d_a, not d_b_one. */
+int fhe_rns_ntt_multiply_bcast(fhe_rns_ntt_t *h, void *d_r, const void *d_a, const void *d_b_one, uint32_t batch);
 /* PolynomialOps::add / sub over RNS polynomials (src/polynomial.cu:36-52), per-limb moduli. */
 int fhe_rns_poly_add(fhe_rns_ntt_t *h, void *d_r, const void *d_a, const void *d_b, uint32_t batch);
 int fhe_rns_poly_sub(fhe_rns_ntt_t *h, void *d_r, const void *d_a, const void *d_b, uint32_t batch);

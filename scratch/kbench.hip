@@ -119,14 +119,14 @@ int main(int argc, char **argv) {
     double ab = 3.0 * bytes;
     report("stream_x4 (full 32B reads)", time_it([&] { hipLaunchKernelGGL(stream_x4_kernel, dim3(8192), dim3(256), 0, 0, (v4u32 *)r, (const v4u32 *)a, (const v4u32 *)b, bytes / 16); }, iters), ab);
     report("stream_dword (NTT access shape)", time_it([&] { hipLaunchKernelGGL(stream_dword_kernel, dim3(polys), dim3(256), 0, 0, (v4u32 *)r, a, b, polys * n); }, iters), ab);
-    report("multiply  lb(256,1)", time_it([&] { hipLaunchKernelGGL((ntt_multiply_kernel<F32S, 13, 1>), dim3(polys), dim3(256), 0, 0, r, a, b, limbs, L); }, iters), ab);
+    report("multiply  lb(256,1)", time_it([&] { hipLaunchKernelGGL((ntt_multiply_kernel<F32S, 13, 1>), dim3(polys), dim3(256), 0, 0, r, a, b, limbs, L, 0u); }, iters), ab);
     CK(hipMemcpy(r2, r, bytes, hipMemcpyDeviceToDevice));
-    report("multiply  lb(256,4)", time_it([&] { hipLaunchKernelGGL((ntt_multiply_kernel<F32S, 13, 4>), dim3(polys), dim3(256), 0, 0, r, a, b, limbs, L); }, iters), ab);
+    report("multiply  lb(256,4)", time_it([&] { hipLaunchKernelGGL((ntt_multiply_kernel<F32S, 13, 4>), dim3(polys), dim3(256), 0, 0, r, a, b, limbs, L, 0u); }, iters), ab);
     CK(hipMemcpy(r2, r, bytes, hipMemcpyDeviceToDevice));
     Limb<F32> *limbs_m = build_m(n, L);
     for (int rep = 0; rep < 3; rep++) {
-        report("multiply  lb(256,4) shoup tw", time_it([&] { hipLaunchKernelGGL((ntt_multiply_kernel<F32S, 13, 4>), dim3(polys), dim3(256), 0, 0, r, a, b, limbs, L); }, iters), ab);
-        report("multiply  lb(256,4) mont  tw", time_it([&] { hipLaunchKernelGGL((ntt_multiply_kernel<F32, 13, 4>), dim3(polys), dim3(256), 0, 0, r, a, b, limbs_m, L); }, iters), ab);
+        report("multiply  lb(256,4) shoup tw", time_it([&] { hipLaunchKernelGGL((ntt_multiply_kernel<F32S, 13, 4>), dim3(polys), dim3(256), 0, 0, r, a, b, limbs, L, 0u); }, iters), ab);
+        report("multiply  lb(256,4) mont  tw", time_it([&] { hipLaunchKernelGGL((ntt_multiply_kernel<F32, 13, 4>), dim3(polys), dim3(256), 0, 0, r, a, b, limbs_m, L, 0u); }, iters), ab);
     }
     // correctness of the last variant vs the plain kernel
     std::vector<uint32_t> h1(1 << 20), h2(1 << 20);

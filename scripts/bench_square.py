@@ -25,3 +25,4 @@ timed(lambda: eng.multiply(bufs[2], bufs[0], bufs[1], B), "multiply(a, b)", 3 * 
 timed(lambda: eng.multiply(bufs[2], bufs[0], bufs[0], B), "multiply(a, a)  [square]", 2 * S * B)
 timed(lambda: eng.ct_multiply(bufs[2], bufs[3], bufs[4], bufs[0], bufs[1], bufs[1], bufs[0], B), "ct_multiply(a, b)", 7 * S * B)
 timed(lambda: eng.ct_multiply(bufs[2], bufs[3], bufs[4], bufs[0], bufs[1], bufs[0], bufs[1], B), "ct_multiply(a, a) [square]", 5 * S * B)
+timed(lambda: eng.multiply_bcast(bufs[2], bufs[0], bufs[1], B), "multiply_bcast(a_i, b)", 2 * S * B)

@@ -1127,3 +1127,20 @@ def test_squaring_forms_match_oracle(eng, oracle, monkeypatch, n, spec, batch, s
     assert np.array_equal(dA0.download(a0.shape), a0) and np.array_equal(dA1.download(a0.shape), a1)      # operands preserved
     e.multiply(dA0, dA0, dA0, batch)                                                                         # in-place square
     assert np.array_equal(dA0.download(a0.shape), rp.polymul(a0, a0, threads=8))
+
+
+@pytest.mark.parametrize("n,spec,batch", [(8192, ("bits", 30, 4), 7), (4096, ("bits", 40, 2), 3), (2048, ("bits", 60, 2), 2), (256, ("bits", 250, 1), 3)])
+def test_multiply_by_one_shared_polynomial(eng, oracle, n, spec, batch):
+    """fhe_rns_ntt_multiply_bcast: every element of a batch times ONE polynomial (a key, a plaintext); equals the element-wise products."""
+    moduli = _moduli(spec, n)
+    e = eng.RnsNttEngine(n, moduli); rp = oracle.RnsPlan(n, moduli)
+    a = rns_poly(1301, moduli, n, batch); b1 = rns_poly(1302, moduli, n, 1)
+    dA, dB, dR = _up(eng, a), _up(eng, b1), eng.DeviceBuffer(a.nbytes)
+    e.multiply_bcast(dR, dA, dB, batch)
+    want = rp.polymul(a, np.ascontiguousarray(np.broadcast_to(b1, a.shape)), threads=8)
+    assert np.array_equal(dR.download(a.shape), want)
+    assert np.array_equal(dA.download(a.shape), a) and np.array_equal(dB.download(b1.shape), b1)
+    e.multiply_bcast(dA, dA, dB, batch)                       # in place over the batch operand
+    assert np.array_equal(dA.download(a.shape), want)
+    with pytest.raises(eng.FheError):
+        e.multiply_bcast(dB, dA, dB, 1)                        # the shared operand must survive
