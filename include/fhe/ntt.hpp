@@ -58,6 +58,10 @@ public:
     void multiply_rns(uint256_t *d_result, const uint256_t *d_a, const uint256_t *d_b, uint32_t batch = 1) {                                // include/ntt.cuh:124-126
         check(fhe_rns_ntt_multiply(h_, d_result, d_a, d_b, batch), "multiply_rns");
     }
+    // addition (not in the reference): ONE polynomial d_b_one multiplied into every element of the batch d_a (a key, a plaintext)
+    void multiply_rns_bcast(uint256_t *d_result, const uint256_t *d_a, const uint256_t *d_b_one, uint32_t batch) {
+        check(fhe_rns_ntt_multiply_bcast(h_, d_result, d_a, d_b_one, batch), "multiply_rns_bcast");
+    }
     // include/ntt.cuh:114-117 (undefined in the reference): d_data is [batch][n] 256-bit integers, d_rns_data [batch][L][n]
     void to_rns(uint256_t *d_rns_data, const uint256_t *d_data, uint32_t batch = 1) { check(fhe_rns_to_rns(h_, d_rns_data, d_data, batch), "to_rns"); }
     void from_rns(uint256_t *d_data, const uint256_t *d_rns_data, uint32_t batch = 1) { check(fhe_rns_from_rns(h_, d_data, d_rns_data, batch), "from_rns"); }
