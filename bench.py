@@ -5,8 +5,8 @@ One "step" = one pass of the hot path over one batch of synthetic RNS polynomial
     r = a (*) b  mod (x^N + 1, q_0..q_{L-1})          fhe_rns_ntt_multiply  (NTTEngine::multiply, src/ntt.cu:49-75)
 for `--batch` polynomial pairs per GPU ([batch][L][N] 32-byte containers, 30-bit NTT primes = log_q 120 / 4).
 
-    python bench.py --gpus N --steps K --warmup W
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
+    python bench.py --gpus N --steps K --warmup W          (N > 1 without a launcher: bench.py starts the N ranks itself)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (N > 1, the driver's form)
 
 Prints ONE JSON line on rank 0.  `value` = polynomial products per second over all GPUs (weak
 scaling: every rank multiplies its own `--batch` pairs; the path has no exchange step, so RCCL is used
@@ -54,9 +54,60 @@ def parse():
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak (default, the driver's contract): every rank processes --batch units; strong: --batch is the TOTAL, split into "
                          "contiguous per-rank blocks (sharding.shard_range)")
+    ap.add_argument("--no-verify", action="store_true", help="skip the per-rank result checksum / oracle spot check (outside the timed region)")
     ap.add_argument("--no-extras", action="store_true",
-                    help="skip the extra leg (op multiply only): batched forward+inverse NTT pairs, the figure the north-star's >= 60 %% target is stated on")
+                    help="skip the extra legs (op multiply only): batched forward+inverse NTT pairs (the figure the north-star's >= 60 %% target is stated on) "
+                         "and the small runs on the other modulus widths")
     return ap.parse_args()
+
+
+def launch_ranks(args):
+    """`bench.py --gpus N` with no launcher around it (WORLD_SIZE unset): start the N ranks as child processes, one per
+    GPU, relay rank 0's JSON line, exit non-zero if any rank fails.  The parent never imports torch and never touches
+    HIP (a process that has initialised the GPU must not fork / exec workers), it only builds the library once so the
+    ranks do not race for the build lock."""
+    import socket
+    import subprocess
+    import tempfile
+    pkg = importlib.import_module("gpu-homomorphic-encryption_amd")
+    pkg.build_library()                          # make + hipcc only; the library is not loaded here
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    tmp = tempfile.mkdtemp(prefix="fhe_bench_")
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        out = open(os.path.join(tmp, f"rank{r}.out"), "w+"); err = open(os.path.join(tmp, f"rank{r}.err"), "w+")
+        procs.append((subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=out, stderr=err), out, err))
+    failed = None
+    while failed is None and any(p.poll() is None for p, _, _ in procs):
+        time.sleep(0.2)
+        for r, (p, _, _) in enumerate(procs):
+            if p.poll() not in (None, 0):
+                failed = r
+    if failed is not None:                       # one rank died: the others would wait in a barrier forever
+        time.sleep(2.0)
+        for p, _, _ in procs:
+            if p.poll() is None:
+                p.kill()
+    rcs = [p.wait() for p, _, _ in procs]
+    lines = []
+    for r, (p, out, err) in enumerate(procs):
+        out.seek(0); err.seek(0)
+        o, e = out.read(), err.read()
+        out.close(); err.close()
+        if r == 0:
+            lines = [l for l in o.splitlines() if l.startswith("{")]
+        if e.strip() and (rcs[r] != 0 or os.environ.get("FHE_BENCH_VERBOSE")):
+            sys.stderr.write(f"--- rank {r} (exit {rcs[r]}) stderr ---\n{e[-4000:]}\n")
+    if any(rcs) or len(lines) != 1:
+        raise SystemExit(f"bench.py: ranks exited with {rcs}; rank 0 printed {len(lines)} JSON lines")
+    line = json.loads(lines[0])
+    if line.get("n_gpus") != args.gpus or line.get("ranks_seen") != args.gpus:
+        raise SystemExit(f"bench.py: asked for {args.gpus} ranks, the line reports n_gpus={line.get('n_gpus')} ranks_seen={line.get('ranks_seen')}")
+    print(lines[0], flush=True)
 
 
 def fill_device(pkg, buf, seed, moduli, n, batch, chunk=64):
@@ -70,6 +121,88 @@ def fill_device(pkg, buf, seed, moduli, n, batch, chunk=64):
         rc = pkg.lib().fhe_hip_memcpy_h2d(buf.ptr + b0 * per, arr.ctypes.data, arr.nbytes)
         if rc:
             raise RuntimeError(pkg.lib().fhe_hip_last_error().decode())
+
+
+def host_poly(seed, moduli, n, b, chunk=64):
+    """The polynomial fill_device(seed, ...) put at batch index b, regenerated on the host: [L][n][4]."""
+    from workload import rns_poly
+    b0 = (b // chunk) * chunk
+    return rns_poly(seed + b0, moduli, n, b - b0 + 1)[b - b0]
+
+
+def download_poly(pkg, buf, b, S):
+    """One RNS polynomial (S bytes at batch index b) of a device buffer as numpy uint64 [S / 32][4]."""
+    import numpy as np
+    out = np.empty(S // 8, dtype=np.uint64)
+    pkg.capi.sync()
+    rc = pkg.lib().fhe_hip_memcpy_d2h(out.ctypes.data, buf.ptr + b * S, S)
+    if rc:
+        raise RuntimeError(pkg.lib().fhe_hip_last_error().decode())
+    return out.reshape(-1, 4)
+
+
+def verify_shard(pkg, op, moduli, n, B, ins, outs, in_seeds):
+    """Outside the timed region: SHA-256 over a sample of THIS rank's result polynomials (first, middle, last of the shard)
+    and, for the ops the CPU oracle restates in one call, the same hash over the oracle's results for the same operands.
+    Returns (checksum, oracle_checksum or None); the oracle is the checker here, never the thing measured."""
+    import hashlib
+    import numpy as np
+    L = len(moduli); S = 32 * n * L
+    sample = sorted({0, B // 2, B - 1})
+    got, want = hashlib.sha256(), hashlib.sha256()
+    rp = None
+    if op in ("multiply", "fwdinv", "ct"):
+        from oracle import pyoracle as orc
+        orc.build()
+        rp = orc.RnsPlan(n, moduli)
+    for b in sample:
+        if op == "fwdinv":
+            res = [download_poly(pkg, ins[0], b, S)]               # K forward+inverse pairs in place: back to the operand
+            exp = [host_poly(in_seeds[0], moduli, n, b).reshape(-1, 4)]
+        else:
+            res = [download_poly(pkg, o, b, S) for o in outs] if outs else [download_poly(pkg, i, b, S) for i in ins[:2]]
+            exp = None
+            if rp is not None:
+                ops = [np.ascontiguousarray(download_poly(pkg, i, b, S).reshape(1, L, n, 4)) for i in ins]
+                if op == "multiply":
+                    exp = [rp.polymul(ops[0], ops[1]).reshape(-1, 4)]
+                else:
+                    exp = [c.reshape(-1, 4) for c in rp.ct_multiply(ops[0], ops[1], ops[2], ops[3])]
+        for r in res:
+            got.update(np.ascontiguousarray(r).tobytes())
+        if exp is not None:
+            for e in exp:
+                want.update(np.ascontiguousarray(e).tobytes())
+    to63 = lambda h: int.from_bytes(h.digest()[:8], "little") >> 1
+    return to63(got), (to63(want) if rp is not None else None)
+
+
+def extra_width_classes(pkg, steps=10, warmup=2):
+    """Small fused-polymul runs on the other modulus widths (outside the headline timing), so that every BENCH record shows
+    them: 3 x 40-bit (FP64 class), 2 x 60-bit and 2 x 64-bit (64-bit integer classes) and 1 x 128-bit, 1 x 250-bit (full-width class)."""
+    out = []
+    n = 8192
+    for bits, L, B in ((40, 3, 512), (60, 2, 512), (64, 2, 512), (128, 1, 128), (250, 1, 64)):
+        try:
+            moduli = pkg.find_ntt_primes(bits, n, L)
+            eng = pkg.RnsNttEngine(n, moduli)
+            S = 32 * n * L
+            dA, dB, dR = (pkg.DeviceBuffer(B * S) for _ in range(3))
+            fill_device(pkg, dA, 51000 + bits, moduli, n, B); fill_device(pkg, dB, 52000 + bits, moduli, n, B)
+            for _ in range(warmup):
+                eng.multiply(dR, dA, dB, B)
+            t = pkg.Timer(); pkg.capi.sync(); t.start(eng)
+            for _ in range(steps):
+                eng.multiply(dR, dA, dB, B)
+            t.stop(eng); pkg.capi.sync()
+            ms = t.elapsed_ms() / steps
+            gbs = 3 * S * B / (ms * 1e-3) / 1e9
+            out.append({"prime_bits": bits, "limbs": L, "batch": B, "width_class": int(eng.width_class), "polymul_per_s": B / (ms * 1e-3),
+                        "achieved_GBps": gbs, "frac": gbs / HBM_PEAK_GBS})
+            del dA, dB, dR, eng
+        except Exception as e:                       # an extra must never take the headline down
+            out.append({"prime_bits": bits, "limbs": L, "error": str(e)[:200]})
+    return out
 
 
 def cpu_baseline(n, moduli, target_core_seconds=16.0):
@@ -122,8 +255,12 @@ def pmc_traffic(kernel_substr, op, n, limbs, bits, batch):
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args)            # the parent only spawns and relays; each child re-enters main() with RANK / WORLD_SIZE set
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     dist = None
     use_dist = world > 1 or os.environ.get("FHE_BENCH_FORCE_DIST") == "1"      # the latter: 1-rank RCCL smoke test
     if use_dist:
@@ -154,8 +291,9 @@ def main():
     n_in, n_out = {"multiply": (2, 1), "fwdinv": (1, 0), "ct": (4, 3), "relin": (3, 0), "ctrelin": (4, 3), "blindrotate": (2, 2)}[args.op]
     ins = [pkg.DeviceBuffer(B * S) for _ in range(n_in)]
     outs = [pkg.DeviceBuffer(B * S) for _ in range(n_out)]
+    in_seeds = [1000 + 4000 * i + rank * 100000 for i in range(n_in)]
     for i, buf in enumerate(ins):
-        fill_device(pkg, buf, 1000 + 4000 * i + rank * 100000, moduli, n, B)
+        fill_device(pkg, buf, in_seeds[i], moduli, n, B)
     for buf in outs:
         buf.zero()
     if args.op == "multiply":
@@ -245,7 +383,7 @@ def main():
     launch_ms = ev_ms / args.steps                   # HIP-event time of one step's launches on the engine stream
     algo_bytes = units_per_poly_bytes * S * B        # 3*S per polymul, 4*S per fwd+inv pair, 7*S per ct-mul (+5*S relin)
     achieved = algo_bytes / (launch_ms * 1e-3) / 1e9
-    width = {1: "u32", 2: "u64", 3: "f64 (exact integers < 2^53)", 4: "u256"}[eng.width_class]
+    width = {1: "u32", 2: "u64", 3: "f64 (exact integers < 2^53)", 4: "u256", 5: "u64 (full-range)"}[eng.width_class]
     metric = "NTT-polymul/sec (N=8192, 4 RNS limbs) + achieved HBM GB/s vs peak"
     if (args.op, n, L) != ("multiply", 8192, 4):
         metric = f"{unit[:-2]}/sec (N={n}, {L} RNS limbs) + achieved HBM GB/s vs peak"
@@ -273,6 +411,24 @@ def main():
         pair_ms = e2 / args.steps
         out["extra_fwd_inv_pairs"] = {"pairs_per_s": B * world / (w2 / args.steps), "achieved_GBps": 4 * S * B / (pair_ms * 1e-3) / 1e9,
                                       "frac": 4 * S * B / (pair_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    # every rank proves its own shard (outside the timed region): result checksum + oracle spot check, gathered to rank 0
+    if not args.no_verify:
+        csum, want = verify_shard(pkg, args.op, moduli, n, B, ins, outs, in_seeds)
+        sums = sharding.gather_ints(dist, csum, device=red_dev)
+        wants = sharding.gather_ints(dist, -1 if want is None else want, device=red_dev)
+        out["ranks_seen"] = len(set(sharding.gather_ints(dist, rank, device=red_dev)))
+        out["shard_checksums"] = [f"{v:016x}" for v in sums]
+        out["oracle_checksums"] = None if want is None else [f"{v:016x}" for v in wants]
+        out["verified"] = None if want is None else (sums == wants)
+        if out["verified"] is False:
+            if rank == 0:
+                print(json.dumps(out), file=sys.stderr, flush=True)
+            raise SystemExit("bench.py: a rank's result differs from the CPU oracle (checksums above)")
+    else:
+        out["ranks_seen"] = len(set(sharding.gather_ints(dist, rank, device=red_dev)))
+    out["dist_backend"] = None if dist is None else (args.dist_backend + (" (RCCL over xGMI)" if args.dist_backend == "nccl" else " (CPU rehearsal)"))
+    if rank == 0 and world == 1 and not args.no_extras and args.op == "multiply":
+        out["extra_width_classes"] = extra_width_classes(pkg)
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.op == "multiply":
         out["cpu_baseline"] = cpu_baseline(n, moduli)
     if rank == 0:

@@ -14,12 +14,12 @@ from .capi import (  # noqa: F401
     FheError, NttEngine, RnsNttEngine, DeviceBuffer, Timer, lib, device_count, find_ntt_primes, find_psi,
     montgomery_inverse, montgomery_params, u256_add_mod, u256_sub_mod, u256_mont_mul, u256_mont_mul_scalar,
     ref_forward_kernel_literal, ref_inverse_kernel_literal, ref_stockham_stage_literal, bit_reverse, sample_uniform_lcg, sample_gaussian_placeholder, gaussian_cdt, poly_mod_switch, negacyclic_reduce,
-    WIDTH_32, WIDTH_52, WIDTH_64, WIDTH_256,
+    WIDTH_32, WIDTH_52, WIDTH_64, WIDTH_256, WIDTH_64X,
 )
 
 __all__ = [
     "build_library", "library_path", "FheError", "NttEngine", "RnsNttEngine", "DeviceBuffer", "Timer", "lib",
     "device_count", "find_ntt_primes", "find_psi", "montgomery_inverse", "montgomery_params", "u256_add_mod",
     "u256_sub_mod", "u256_mont_mul", "u256_mont_mul_scalar", "ref_forward_kernel_literal", "ref_inverse_kernel_literal", "ref_stockham_stage_literal", "bit_reverse", "sample_uniform_lcg", "sample_gaussian_placeholder",
-    "gaussian_cdt", "poly_mod_switch", "negacyclic_reduce", "WIDTH_32", "WIDTH_52", "WIDTH_64", "WIDTH_256",
+    "gaussian_cdt", "poly_mod_switch", "negacyclic_reduce", "WIDTH_32", "WIDTH_52", "WIDTH_64", "WIDTH_256", "WIDTH_64X",
 ]

@@ -7,7 +7,7 @@ import numpy as np
 
 from .build import library_path
 
-WIDTH_32, WIDTH_64, WIDTH_52, WIDTH_256 = 1, 2, 3, 4
+WIDTH_32, WIDTH_64, WIDTH_52, WIDTH_256, WIDTH_64X = 1, 2, 3, 4, 5
 _lib = None
 
 U64x4 = ctypes.c_uint64 * 4
@@ -48,6 +48,7 @@ def lib():
         "fhe_montgomery_inverse": ([U64x4, U64x4], ci),
         "fhe_montgomery_params": ([U64x4, U64x4, U64x4], ci),
         "fhe_find_ntt_primes": ([u32, u32, u32, P(u64)], ci),
+        "fhe_find_ntt_primes_wide": ([u32, u32, u32, vp], ci),
         "fhe_find_psi": ([u32, U64x4, U64x4], ci),
         "fhe_u256_add_mod": ([vp, vp, vp, U64x4, sz, vp], ci),
         "fhe_u256_sub_mod": ([vp, vp, vp, U64x4, sz, vp], ci),
@@ -136,6 +137,9 @@ def montgomery_params(q):
 
 
 def find_ntt_primes(bits, n, count):
+    if bits > 64:
+        out = (U64x4 * count)(); _check(lib().fhe_find_ntt_primes_wide(bits, n, count, ctypes.cast(out, ctypes.c_void_p)))
+        return [_int(x) for x in out]
     out = (ctypes.c_uint64 * count)(); _check(lib().fhe_find_ntt_primes(bits, n, count, out)); return [int(x) for x in out]
 
 

@@ -132,6 +132,14 @@ extern "C" int fhe_find_ntt_primes(uint32_t bits, uint32_t n, uint32_t count, ui
         return fail(FHE_ERR_INVALID_ARG, "no such primes (need 4 <= bits <= 64, n a power of two, 2n < 2^(bits-1))");
     return FHE_OK;
 }
+extern "C" int fhe_find_ntt_primes_wide(uint32_t bits, uint32_t n, uint32_t count, uint64_t (*primes_out)[4]) {
+    if (!primes_out || !count) return fail(FHE_ERR_INVALID_ARG, "null output / zero count");
+    std::vector<U256> ps(count);
+    if (!fhe_host::find_ntt_primes_wide(bits, n, count, ps.data()))
+        return fail(FHE_ERR_INVALID_ARG, "no such primes (need 4 <= bits <= 255, n a power of two, 2n < 2^(bits-2))");
+    for (uint32_t i = 0; i < count; i++) std::memcpy(primes_out[i], ps[i].w, 32);
+    return FHE_OK;
+}
 extern "C" int fhe_find_psi(uint32_t n, const uint64_t q[4], uint64_t psi[4]) {
     if (!q || !psi) return fail(FHE_ERR_INVALID_ARG, "null argument");
     if (n < 2 || (n & (n - 1))) return fail(FHE_ERR_INVALID_ARG, "n must be a power of two");
@@ -341,6 +349,32 @@ static int build_limbs64(fhe_rns_ntt *h, const std::vector<fhe_host::NttConstant
     return upload(h, limbs, &h->d_limbs);
 }
 
+static int build_limbs64x(fhe_rns_ntt *h, const std::vector<fhe_host::NttConstants> &cs) {
+    std::vector<fhe_dev::Limb64X> limbs(h->L);
+    for (uint32_t l = 0; l < h->L; l++) {
+        const fhe_host::NttConstants &c = cs[l];
+        const uint64_t q = c.q.w[0], n = h->n;
+        auto mulq = [q](uint64_t a, uint64_t b) { return (uint64_t)(((fhe_host::u128)a * b) % q); };
+        const uint64_t two64 = (uint64_t)((((fhe_host::u128)1) << 64) % q), two128 = mulq(two64, two64);
+        std::vector<uint64_t> tw(n), itw(n);               // Montgomery form: w * 2^64 mod q
+        for (uint32_t k = 0; k < n; k++) { tw[k] = mulq(c.tw[k].w[0], two64); itw[k] = mulq(c.itw[k].w[0], two64); }
+        fhe_dev::Limb64X &P = limbs[l];
+        std::memset(&P, 0, sizeof(P));
+        P.q = q; P.q2 = 0;                                 // 2q does not fit; nothing on this field reads it
+        uint64_t x = 1; for (int i = 0; i < 6; i++) x *= 2 - q * x;               // q^-1 mod 2^64
+        P.qinv = x;
+        const uint64_t ninv = c.n_inv.w[0], nw = mulq(ninv, c.itw[1].w[0]);
+        P.r1 = two128;
+        P.ninv = mulq(ninv, two64); P.ninvw = mulq(nw, two64);
+        P.ninv_r = mulq(ninv, two128); P.ninvw_r = mulq(nw, two128);
+        P.r1_s = P.ninv_s = P.ninvw_s = P.ninv_r_s = P.ninvw_r_s = x;              // the companion slots carry q^-1 (F64X::inv_last)
+        void *d = nullptr; int rc;
+        if ((rc = upload(h, tw, &d))) return rc; P.tw = (const uint64_t *)d;
+        if ((rc = upload(h, itw, &d))) return rc; P.itw = (const uint64_t *)d;
+    }
+    return upload(h, limbs, &h->d_limbs);
+}
+
 static int build_limbs52(fhe_rns_ntt *h, const std::vector<fhe_host::NttConstants> &cs) {
     std::vector<fhe_dev::Limb52> limbs(h->L);
     for (uint32_t l = 0; l < h->L; l++) {
@@ -431,7 +465,8 @@ static int create_impl(fhe_rns_ntt **out, uint32_t n, const uint64_t (*moduli)[4
     if (floor_w >= 256) h->width = FHE_WIDTH_256;
     else if (lds_size && max_bits <= 30 && floor_w < 52) h->width = FHE_WIDTH_32;
     else if (lds_size && h->log_n <= 14 && max_bits <= 43 && floor_w < 64) h->width = FHE_WIDTH_52;
-    else if (lds_size && h->log_n <= 14 && max_bits <= 62) h->width = FHE_WIDTH_64;
+    else if (lds_size && h->log_n <= 14 && max_bits <= 62 && floor_w < 65) h->width = FHE_WIDTH_64;
+    else if (lds_size && h->log_n <= 14 && max_bits <= 64) h->width = FHE_WIDTH_64X;      // FHE_HIP_FORCE_WIDTH=65 forces it
     else h->width = FHE_WIDTH_256;
 #define TRY_OR_DESTROY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { destroy_impl(h); return fail(FHE_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); } } while (0)
     TRY_OR_DESTROY(hipGetDevice(&h->device));
@@ -442,7 +477,7 @@ static int create_impl(fhe_rns_ntt **out, uint32_t n, const uint64_t (*moduli)[4
     TRY_OR_DESTROY(hipMemset(h->d_flag, 0, sizeof(uint32_t)));
 #undef TRY_OR_DESTROY
     rc = h->width == FHE_WIDTH_32 ? build_limbs32(h, cs) : h->width == FHE_WIDTH_52 ? build_limbs52(h, cs)
-         : h->width == FHE_WIDTH_64 ? build_limbs64(h, cs) : build_limbs256(h, cs);
+         : h->width == FHE_WIDTH_64 ? build_limbs64(h, cs) : h->width == FHE_WIDTH_64X ? build_limbs64x(h, cs) : build_limbs256(h, cs);
     if (rc) { destroy_impl(h); return rc; }
     *out = h;
     return FHE_OK;
@@ -501,9 +536,12 @@ static int run256_ew(fhe_rns_ntt *h, void *r, const void *a, const void *b, uint
 }
 
 // ---- LDS-resident path launchers (kernels live in lds_inst.hip, one object per (field, log2 n)) ---------
+static int lds_width_id(const fhe_rns_ntt *h) {
+    return h->width == FHE_WIDTH_32 ? 32 : h->width == FHE_WIDTH_52 ? 52 : h->width == FHE_WIDTH_64 ? 64 : 65;
+}
 static int lds_run(fhe_rns_ntt *h, int op, void *r0, void *r1, void *r2, const void *a0, const void *a1, const void *b0,
                    const void *b1, uint32_t polys, const char *what, uint32_t b_polys = 0) {
-    fhe_dev::lds_launch_fn fn = fhe_dev::lds_lookup(h->width == FHE_WIDTH_32 ? 32 : h->width == FHE_WIDTH_52 ? 52 : 64, (int)h->log_n);
+    fhe_dev::lds_launch_fn fn = fhe_dev::lds_lookup(lds_width_id(h), (int)h->log_n);
     if (!fn) return fail(FHE_ERR_UNSUPPORTED, "transform size outside the LDS-resident range");
     fhe_dev::LdsArgs A{op, r0, r1, r2, a0, a1, b0, b1, h->d_limbs, h->L, polys, h->stream};
     A.single_transforms = getenv("FHE_HIP_NO_PAIRED_TRANSFORMS") != nullptr;
@@ -548,6 +586,7 @@ static int do_ew(fhe_rns_ntt *h, void *r, const void *a, const void *b, uint32_t
     if (h->width == FHE_WIDTH_32) return lds_ew<fhe_dev::F32, OP>(h, r, a, b, polys, what);
     if (h->width == FHE_WIDTH_52) return lds_ew<fhe_dev::F52, OP>(h, r, a, b, polys, what);
     if (h->width == FHE_WIDTH_64) return lds_ew<fhe_dev::F64, OP>(h, r, a, b, polys, what);
+    if (h->width == FHE_WIDTH_64X) return lds_ew<fhe_dev::F64X, OP>(h, r, a, b, polys, what);
     return run256_ew<OP>(h, r, a, b, polys, what);
 }
 static int do_multiply(fhe_rns_ntt *h, void *d_r, const void *d_a, const void *d_b, uint32_t batch) {
@@ -670,6 +709,7 @@ extern "C" int fhe_rns_check_canonical(fhe_rns_ntt_t *h, const void *d_data, uin
     if (h->width == FHE_WIDTH_32) rc = lds_check<fhe_dev::F32>(h, d_data, polys);
     else if (h->width == FHE_WIDTH_52) rc = lds_check<fhe_dev::F52>(h, d_data, polys);
     else if (h->width == FHE_WIDTH_64) rc = lds_check<fhe_dev::F64>(h, d_data, polys);
+    else if (h->width == FHE_WIDTH_64X) rc = lds_check<fhe_dev::F64X>(h, d_data, polys);
     else {
         size_t count = (size_t)polys * h->n;
         hipLaunchKernelGGL(fhe_dev::check256_kernel, dim3(ew_grid(count)), dim3(256), 0, h->stream, (const fhe_dev::u256 *)d_data,
@@ -728,6 +768,7 @@ static int pack_relin_keys_t(fhe_rns_ntt *h, fhe_relin_keys *rk) {
 static int pack_relin_keys(fhe_rns_ntt *h, fhe_relin_keys *rk) {
     if (h->width == FHE_WIDTH_32) return pack_relin_keys_t<fhe_dev::F32>(h, rk);
     if (h->width == FHE_WIDTH_52) return pack_relin_keys_t<fhe_dev::F52>(h, rk);
+    if (h->width == FHE_WIDTH_64X) return pack_relin_keys_t<fhe_dev::F64X>(h, rk);
     return pack_relin_keys_t<fhe_dev::F64>(h, rk);
 }
 
@@ -768,6 +809,10 @@ extern "C" int fhe_relin_keys_create(fhe_rns_ntt_t *h, fhe_relin_keys_t **out, u
         for (const U256 &q : h->moduli) { fhe_host::u128 v = q.w[0]; q_min = v < q_min ? v : q_min; q_max = v > q_max ? v : q_max; }
         fhe_host::u128 digit_bound = decomp_bits >= 64 ? q_max : (((fhe_host::u128)1 << decomp_bits) < q_max ? ((fhe_host::u128)1 << decomp_bits) : q_max);
         digits_fit = digit_bound <= 4 * q_min;
+    } else if (h->width == FHE_WIDTH_64X) {   // canonical butterflies: a digit must be a residue of q_i as it stands
+        fhe_host::u128 q_min = ~(fhe_host::u128)0, q_max = 0;
+        for (const U256 &q : h->moduli) { fhe_host::u128 v = q.w[0]; q_min = v < q_min ? v : q_min; q_max = v > q_max ? v : q_max; }
+        digits_fit = (decomp_bits >= 64 ? q_max : (((fhe_host::u128)1 << decomp_bits) < q_max ? ((fhe_host::u128)1 << decomp_bits) : q_max)) <= q_min;
     }
     if (!rc && h->width != FHE_WIDTH_256 && digits_fit && !getenv("FHE_HIP_NO_FUSED_KEYSWITCH")) {
         rc = pack_relin_keys(h, rk);
@@ -801,6 +846,7 @@ static int relin_embed_mac(fhe_rns_ntt *h, const fhe_relin_keys *rk, char *D, ch
     if (h->width == FHE_WIDTH_32) return relin_embed_mac_lds<fhe_dev::F32>(h, rk, D, acc0, acc1, c2, chunk, phase);
     if (h->width == FHE_WIDTH_52) return relin_embed_mac_lds<fhe_dev::F52>(h, rk, D, acc0, acc1, c2, chunk, phase);
     if (h->width == FHE_WIDTH_64) return relin_embed_mac_lds<fhe_dev::F64>(h, rk, D, acc0, acc1, c2, chunk, phase);
+    if (h->width == FHE_WIDTH_64X) return relin_embed_mac_lds<fhe_dev::F64X>(h, rk, D, acc0, acc1, c2, chunk, phase);
     const uint32_t LK = h->L * rk->K;
     if (phase == 0) {
         size_t total = (size_t)LK * chunk * h->L * h->n;
@@ -821,7 +867,7 @@ extern "C" int fhe_ct_relinearize(fhe_rns_ntt_t *h, const fhe_relin_keys_t *rk, 
     if (rk->owner != h) return fail(FHE_ERR_INVALID_ARG, "ct_relinearize: keys were imported for a different engine");
     if (d_c0 == d_c1 || d_c0 == d_c2 || d_c1 == d_c2) return fail(FHE_ERR_INVALID_ARG, "ct_relinearize: components must be distinct buffers");
     if (rk->d_pkb) {   // word-sized paths: one fused launch
-        fhe_dev::lds_launch_fn fn = fhe_dev::lds_lookup(h->width == FHE_WIDTH_32 ? 32 : h->width == FHE_WIDTH_52 ? 52 : 64, (int)h->log_n);
+        fhe_dev::lds_launch_fn fn = fhe_dev::lds_lookup(lds_width_id(h), (int)h->log_n);
         if (!fn) return fail(FHE_ERR_UNSUPPORTED, "transform size outside the LDS-resident range");
         fhe_dev::LdsArgs A{fhe_dev::LDS_KEYSWITCH, d_c0, d_c1, nullptr, d_c2, nullptr, nullptr, nullptr, h->d_limbs, h->L, batch * h->L, h->stream};
         A.kb = rk->d_pkb; A.ka = rk->d_pka; A.K = rk->K; A.w = rk->decomp_bits;
@@ -942,6 +988,7 @@ extern "C" int fhe_rns_to_rns(fhe_rns_ntt_t *h, void *d_rns, const void *d_value
         if (h->width == FHE_WIDTH_32) return to_rns_word<fhe_dev::F32, uint32_t>(h, d_rns, d_values, batch);
         if (h->width == FHE_WIDTH_52) return to_rns_word<fhe_dev::F52, uint32_t>(h, d_rns, d_values, batch);
         if (h->width == FHE_WIDTH_64) return to_rns_word<fhe_dev::F64, uint64_t>(h, d_rns, d_values, batch);
+        if (h->width == FHE_WIDTH_64X) return to_rns_word<fhe_dev::F64X, uint64_t>(h, d_rns, d_values, batch);
     }
     if ((rc = ensure_crt(h))) return rc;
     const size_t count = (size_t)batch * h->n;
@@ -980,6 +1027,7 @@ extern "C" int fhe_rns_from_rns(fhe_rns_ntt_t *h, void *d_values, const void *d_
         if (h->width == FHE_WIDTH_32) return from_rns_word<fhe_dev::F32>(h, d_values, d_rns, batch);
         if (h->width == FHE_WIDTH_52) return from_rns_word<fhe_dev::F52>(h, d_values, d_rns, batch);
         if (h->width == FHE_WIDTH_64) return from_rns_word<fhe_dev::F64>(h, d_values, d_rns, batch);
+        if (h->width == FHE_WIDTH_64X) return from_rns_word<fhe_dev::F64X>(h, d_values, d_rns, batch);
     }
     const size_t count = (size_t)batch * h->n;
     hipLaunchKernelGGL(fhe_dev::from_rns_kernel, dim3(ew_grid(count)), dim3(256), 0, h->stream, (fhe_dev::u256 *)d_values, (const fhe_dev::u256 *)d_rns,
@@ -1039,6 +1087,7 @@ extern "C" int fhe_rns_rescale_drop_last(fhe_rns_ntt_t *h, void *d_out, const vo
         if (h->width == FHE_WIDTH_32) return rescale_word<fhe_dev::F32>(h, d_out, d_in, batch);
         if (h->width == FHE_WIDTH_52) return rescale_word<fhe_dev::F52>(h, d_out, d_in, batch);
         if (h->width == FHE_WIDTH_64) return rescale_word<fhe_dev::F64>(h, d_out, d_in, batch);
+        if (h->width == FHE_WIDTH_64X) return rescale_word<fhe_dev::F64X>(h, d_out, d_in, batch);
     }
     if ((rc = ensure_crt(h))) return rc;
     if (!h->d_rescale) {
@@ -1066,6 +1115,7 @@ extern "C" int fhe_rns_fast_base_convert(fhe_rns_ntt_t *h, fhe_rns_ntt_t *target
     if (h->width == target->width && h->width != FHE_WIDTH_256 && !getenv("FHE_HIP_NO_WORD_CONVERSIONS")) {
         if (h->width == FHE_WIDTH_32) return base_convert_word<fhe_dev::F32>(h, target, d_out, d_in, batch);
         if (h->width == FHE_WIDTH_52) return base_convert_word<fhe_dev::F52>(h, target, d_out, d_in, batch);
+        if (h->width == FHE_WIDTH_64X) return base_convert_word<fhe_dev::F64X>(h, target, d_out, d_in, batch);
         return base_convert_word<fhe_dev::F64>(h, target, d_out, d_in, batch);
     }
     if ((rc = ensure_crt(h)) || (rc = ensure_crt(target))) return rc;
@@ -1107,6 +1157,7 @@ extern "C" int fhe_rns_monomial_mul_sub(fhe_rns_ntt_t *h, void *d_out, const voi
     if (h->width == FHE_WIDTH_32) return monomial_lds<fhe_dev::F32>(h, d_out, d_in, d_shifts, batch);
     if (h->width == FHE_WIDTH_52) return monomial_lds<fhe_dev::F52>(h, d_out, d_in, d_shifts, batch);
     if (h->width == FHE_WIDTH_64) return monomial_lds<fhe_dev::F64>(h, d_out, d_in, d_shifts, batch);
+    if (h->width == FHE_WIDTH_64X) return monomial_lds<fhe_dev::F64X>(h, d_out, d_in, d_shifts, batch);
     size_t count = (size_t)batch * h->L * h->n;
     hipLaunchKernelGGL(fhe_dev::monomial_mul_sub256_kernel, dim3(ew_grid(count)), dim3(256), 0, h->stream, (fhe_dev::u256 *)d_out,
                        (const fhe_dev::u256 *)d_in, d_shifts, (const fhe_dev::Limb256 *)h->d_limbs, h->L, h->log_n, count);
@@ -1124,7 +1175,7 @@ static int blind_rotate_step_general(fhe_rns_ntt_t *h, const fhe_relin_keys_t *r
 // One step as ONE launch (word-sized classes with packed rows): (out0, out1) = (in0, in1) + ExtProd((X^a - 1) * in, RGSW).
 static int blind_rotate_step_fused(fhe_rns_ntt_t *h, const fhe_relin_keys_t *r0, const fhe_relin_keys_t *r1, void *out0, void *out1, const void *in0,
                                    const void *in1, const uint32_t *d_shifts, uint32_t batch) {
-    fhe_dev::lds_launch_fn fn = fhe_dev::lds_lookup(h->width == FHE_WIDTH_32 ? 32 : h->width == FHE_WIDTH_52 ? 52 : 64, (int)h->log_n);
+    fhe_dev::lds_launch_fn fn = fhe_dev::lds_lookup(lds_width_id(h), (int)h->log_n);
     if (!fn) return fail(FHE_ERR_UNSUPPORTED, "transform size outside the LDS-resident range");
     fhe_dev::LdsArgs A{fhe_dev::LDS_EXTPROD, out0, out1, nullptr, in0, in1, nullptr, nullptr, h->d_limbs, h->L, batch * h->L, h->stream};
     A.kb = r0->d_pkb; A.ka = r0->d_pka; A.kb1 = r1->d_pkb; A.ka1 = r1->d_pka; A.K = r0->K; A.w = r0->decomp_bits; A.shifts = d_shifts;

@@ -212,4 +212,19 @@ inline bool find_ntt_primes(uint32_t bits, uint32_t n, uint32_t count, uint64_t 
     return found == count;
 }
 
+// The same search for any width: `count` smallest primes >= 2^(bits-1) with q = 1 (mod 2n), bits in [lb(2n)+2, 255].
+inline bool find_ntt_primes_wide(uint32_t bits, uint32_t n, uint32_t count, U256 *out) {
+    if (bits < 4 || bits > 255 || n < 2 || (n & (n - 1))) return false;
+    uint32_t log2n = 1; while ((1u << log2n) < 2 * n) log2n++;
+    if (log2n + 1 >= bits) return false;
+    U256 q, step((uint64_t)2 * n), hi;
+    q.w[(bits - 1) >> 6] = 1ull << ((bits - 1) & 63);          // 2^(bits-1) = 0 (mod 2n)
+    if (bits < 256) { if (bits == 255) { hi.w[3] = 1ull << 63; } else hi.w[bits >> 6] = 1ull << (bits & 63); }
+    add_to(q, q, U256(1));
+    uint32_t found = 0;
+    for (; found < count && cmp(q, hi) < 0; add_to(q, q, step))
+        if (is_prime(q)) out[found++] = q;
+    return found == count;
+}
+
 }  // namespace fhe_host

@@ -49,7 +49,7 @@ struct LdsArgs {
 
 typedef void (*lds_launch_fn)(const LdsArgs &);
 
-// width: 32, 52 or 64.  nullptr when the instance does not exist.
+// width: 32, 52, 64 or 65 (= F64X, full-range 64-bit).  nullptr when the instance does not exist.
 lds_launch_fn lds_lookup(int width, int log_n);
 
 }  // namespace fhe_dev

@@ -153,6 +153,57 @@ struct F64 : IntField<F64, uint64_t, ulonglong2> {
     __device__ static __forceinline__ bool any_nonzero(const V16 &v) { return (v.x | v.y) != 0; }
 };
 
+// Full-range 64-bit field: ANY odd prime q < 2^64 (in practice 2^62 <= q < 2^64, the primes the lazy F64 ranges cannot hold: its
+// [0, 4q) / [0, 2q) bookkeeping needs 4q < 2^64).  Values stay canonical in [0, q) through every butterfly; sums and differences go
+// through the carry / borrow (addm / subm), products are canonical Montgomery products hi(a*b) - hi(m*q) (+ q on borrow), so
+// twiddles are single words w * 2^64 mod q (8 bytes instead of F64's 16-byte Shoup pairs).  Limb<F64X> holds: qinv = q^-1 mod 2^64,
+// r1 = 2^128 mod q, ninv / ninvw = n^-1 (* itw[1]) * 2^64, ninv_r / ninvw_r = the same * 2^128; every *_s slot holds qinv again
+// (inv_last receives no qinv of its own, and there are no Shoup companions on this field).
+struct F64X : IntField<F64X, uint64_t, uint64_t> {
+    using V16 = v2u64;
+    static constexpr int MAX_LOGN = 14;
+    static constexpr int MULT_MINW = 2;
+    __device__ static __forceinline__ E addm(E a, E b, E q) { E s = a + b; return (s < a || s >= q) ? s - q : s; }
+    __device__ static __forceinline__ E subm(E a, E b, E q) { E d = a - b; return a < b ? d + q : d; }
+    // a*b*2^-64 mod q, canonical, for a*b < q*2^64 (one factor below q, the other any 64-bit word)
+    __device__ static __forceinline__ E mont_mul(E a, E b, E q, E qinv) {
+        const E lo = a * b, hi = __umul64hi(a, b);
+        const E mh = __umul64hi(lo * qinv, q);
+        const E d = hi - mh;
+        return hi < mh ? d + q : d;
+    }
+    template <class L> __device__ static __forceinline__ E tw_mul(E x, const TW &w, const L &P) { return mont_mul(x, w, P.q, P.qinv); }
+    template <class L> __device__ static __forceinline__ void fwd_bfly(E &x0, E &x1, const TW &w, const L &P) {
+        const E T = mont_mul(x1, w, P.q, P.qinv), X = x0;
+        x0 = addm(X, T, P.q);
+        x1 = subm(X, T, P.q);
+    }
+    template <class L> __device__ static __forceinline__ void inv_bfly(E &x0, E &x1, const TW &w, const L &P) {
+        const E X = x0, Y = x1;
+        x0 = addm(X, Y, P.q);
+        x1 = mont_mul(subm(X, Y, P.q), w, P.q, P.qinv);
+    }
+    __device__ static __forceinline__ void inv_last(E &x0, E &x1, E q, E, E ninv, E qinv, E ninvw, E) {
+        const E X = x0, Y = x1;
+        x0 = mont_mul(addm(X, Y, q), ninv, q, qinv);
+        x1 = mont_mul(subm(X, Y, q), ninvw, q, qinv);
+    }
+    __device__ static __forceinline__ E canon_fwd(E x, E, E, E) { return x; }
+    __device__ static __forceinline__ E canon_inv(E x, E) { return x; }
+    __device__ static __forceinline__ E pw_mul(E a, E b, E q, E qinv) { return mont_mul(a, b, q, qinv); }
+    __device__ static __forceinline__ E pw_mul2(E a0, E b0, E a1, E b1, E q, E, E qinv) { return addm(mont_mul(a0, b0, q, qinv), mont_mul(a1, b1, q, qinv), q); }
+    __device__ static __forceinline__ E pw_add(E a, E b, E q, E) { return addm(a, b, q); }
+    template <class L> __device__ static __forceinline__ E ew_mul(E x, E y, const L &P) { return mont_mul(mont_mul(x, y, P.q, P.qinv), P.r1, P.q, P.qinv); }
+    __device__ static __forceinline__ E ew_add(E x, E y, E q) { return addm(x, y, q); }
+    __device__ static __forceinline__ E ew_sub(E x, E y, E q) { return subm(x, y, q); }
+    template <class L> __device__ static __forceinline__ E to_pw_operand(E x, const L &P) { return mont_mul(x, P.r1, P.q, P.qinv); }
+    __device__ static __forceinline__ E load_low(const void *container) { return __builtin_nontemporal_load((const E *)container); }
+    __device__ static __forceinline__ V16 pack(E v) { V16 o = {v, 0ull}; return o; }
+    __device__ static __forceinline__ uint64_t low(const V16 &v) { return v.x; }
+    __device__ static __forceinline__ bool upper_nonzero(const V16 &v) { return v.y != 0; }
+    __device__ static __forceinline__ bool any_nonzero(const V16 &v) { return (v.x | v.y) != 0; }
+};
+
 // Residues as exact integers in IEEE doubles (q < 2^43).  x*w mod q with the precomputed companion wq = fl(w/q):
 //   h = fl(x*w), l = x*w - h (exact, one FMA), c = rint(fl(x*wq)), d = h - c*q (exact, one FMA), r = d + l.
 // For |x| < 2^49: |fl(x*wq) - x*w/q| < 2^-2, so c is within 1 of the nearest integer and |r| < 0.76 q; h - c*q and l are
@@ -246,6 +297,7 @@ struct Limb {
 };
 using Limb32 = Limb<F32>;
 using Limb64 = Limb<F64>;
+using Limb64X = Limb<F64X>;
 using Limb52 = Limb<F52>;
 
 template <int LOGN>

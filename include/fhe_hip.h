@@ -51,7 +51,9 @@ typedef enum fhe_width_class {
     FHE_WIDTH_32 = 1,    /* every q < 2^30 : 32-bit lazy Shoup butterflies, whole NTT in LDS */
     FHE_WIDTH_64 = 2,    /* every q < 2^62 : 64-bit lazy butterflies, whole NTT in LDS */
     FHE_WIDTH_52 = 3,    /* every q < 2^43 : residues as exact integers in doubles, FP64 FMA butterflies, whole NTT in LDS */
-    FHE_WIDTH_256 = 4    /* anything else < 2^255 : full 4x64-bit Montgomery (R = 2^256), multi-pass */
+    FHE_WIDTH_256 = 4,   /* anything else < 2^255 : full 4x64-bit Montgomery (R = 2^256), multi-pass */
+    FHE_WIDTH_64X = 5    /* every q < 2^64 (some q >= 2^62): 64-bit canonical butterflies (carry-aware add / sub, one-word
+                            Montgomery twiddles), whole NTT in LDS */
 } fhe_width_class;
 
 typedef struct fhe_ntt fhe_ntt_t;          /* replaces fhe::NTTEngine      (include/ntt.cuh:72-103)  */
@@ -81,6 +83,8 @@ int fhe_montgomery_params(const uint64_t q[4], uint64_t r_squared[4], uint64_t i
 /* find_ntt_prime / generate_rns_primes (include/rns.cuh:139-149; src/rns.cu:183-209 are stubs):
  * the `count` smallest primes >= 2^(bits-1) with q = 1 (mod 2n); bits <= 64. */
 int fhe_find_ntt_primes(uint32_t bits, uint32_t n, uint32_t count, uint64_t *primes_out);
+/* the same search for moduli of any width the engine accepts (bits <= 255), as 4 x u64 little-endian containers */
+int fhe_find_ntt_primes_wide(uint32_t bits, uint32_t n, uint32_t count, uint64_t (*primes_out)[4]);
 /* find_primitive_root (src/ntt.cu:110-114 is a stub): primitive 2n-th root of unity psi, chosen as
  * the first x^((q-1)/2n), x = 2,3,..., whose n-th power is q-1. */
 int fhe_find_psi(uint32_t n, const uint64_t q[4], uint64_t psi[4]);

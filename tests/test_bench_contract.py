@@ -37,6 +37,36 @@ def test_default_workload_line_has_every_contract_field():
     assert b["kind"] == "port" and b["unit"] == "polymul/s" and b["value"] > 0 and b["cores"] >= 1 and "sample" in b
     assert b["narrow_port"]["value"] > b["value"]
     assert d["extra_fwd_inv_pairs"]["pairs_per_s"] > 0
+    # every rank proves its shard: result checksum == the oracle's on the sampled polynomials
+    assert d["ranks_seen"] == 1 and d["verified"] is True and d["shard_checksums"] == d["oracle_checksums"] and len(d["shard_checksums"]) == 1
+    x = {(e["prime_bits"], e["limbs"]): e for e in d["extra_width_classes"]}
+    assert set(x) == {(40, 3), (60, 2), (64, 2), (128, 1), (250, 1)} and all("error" not in e and e["polymul_per_s"] > 0 for e in x.values())
+    assert x[(250, 1)]["width_class"] == 4 and x[(40, 3)]["width_class"] == 3
+
+
+@pytest.mark.gpu
+def test_gpus_2_spawns_two_ranks_and_verifies_both_shards():
+    """`bench.py --gpus 2` with no launcher around it starts the two ranks itself (here both on device 0 over gloo: the one-GPU
+    rehearsal of the driver's multi-GPU run) and reports both ranks' checksums, each equal to the CPU oracle's."""
+    d = _run("--gpus", "2", "--dist-backend", "gloo", "--device-override", "0", "--batch", "256", "--steps", "3", "--warmup", "1")
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["verified"] is True
+    assert len(d["shard_checksums"]) == 2 and d["shard_checksums"] == d["oracle_checksums"]
+    assert d["shard_checksums"][0] != d["shard_checksums"][1]            # every rank works on its own data
+    assert d["config"]["batch_per_gpu"] == 256 and d["config"]["parallelism"] == "batch-shard x2"
+    assert abs(d["value"] - 2 * 256 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
+    assert "cpu_baseline" not in d and "gloo" in d["dist_backend"]
+
+
+def test_gpus_n_without_a_device_fails_loudly():
+    """CPU container: the launcher starts N ranks, they find no HIP device, the parent exits non-zero (no silent 1-rank line)."""
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--steps", "1", "--warmup", "0",
+                          "--batch", "2"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    import importlib
+    pkg = importlib.import_module("gpu-homomorphic-encryption_amd")
+    if pkg.device_count() > 0:
+        pytest.skip("a GPU is present; covered by the gpu-marked test")
+    assert res.returncode != 0 and not [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert "ranks exited" in res.stderr or "no HIP device" in res.stderr
 
 
 @pytest.mark.gpu
