@@ -25,7 +25,7 @@ def fail(what, **kw):
 
 while time.time() - t0 < budget:
     log_n = int(rng.integers(11, 16)); n = 1 << log_n
-    bits = int(rng.choice([30, 30, 40, 60])) if log_n <= 14 else 30
+    bits = int(rng.choice([30, 30, 40, 60, 64])) if log_n <= 14 else 30
     L = int(rng.integers(1, 5))
     batch = int(rng.integers(1, 13)) if log_n <= 13 else int(rng.integers(1, 4))
     moduli = pkg.find_ntt_primes(bits, n, L)

@@ -80,12 +80,18 @@ CASES = [
     (8192, ("bits", 43, 2), 2, 3),              # widest primes the FP64 path accepts
     (2048, ("bits", 31, 2), 2, 3),              # just above the 32-bit path
     (4096, ("bits", 44, 1), 1, 2),              # just above the FP64 path -> 64-bit integer path
-    (8192, ("bits", 64, 1), 1, 4),              # 64-bit prime: too wide for the lazy 64-bit path
+    (8192, ("bits", 64, 1), 1, 5),              # 64-bit prime: too wide for the lazy 64-bit path -> full-range 64-bit path (F64X)
+    (2048, ("bits", 63, 2), 2, 5),
+    (16384, ("bits", 64, 2), 1, 5),
+    (4096, ("mix", (64, 1), (50, 1), (63, 1)), 2, 5),   # one wide prime pulls the whole basis onto the full-range path
+    (32768, ("bits", 64, 1), 1, 4),             # beyond the LDS range of 8-byte residues: general path
     (65536, ("bits", 30, 1), 1, 4),             # larger than LDS: general path
 ]
 
 
 def _moduli(spec, n):
+    if isinstance(spec, tuple) and spec[0] == "mix":
+        return [q for bits, cnt in spec[1:] for q in nm.ntt_primes(bits, n, cnt)]
     if isinstance(spec, tuple):
         return nm.ntt_primes(spec[1], n, spec[2])
     return list(spec)
@@ -135,7 +141,7 @@ def test_forward_inverse_multiply_match_oracle(eng, oracle, n, spec, batch, widt
 
 
 @pytest.mark.parametrize("n,spec,batch", [(2048, [40961], 2), (8192, ("bits", 30, 4), 2), (4096, ("bits", 60, 2), 1),
-                                          (16384, ("bits", 40, 6), 1), (256, ("bits", 250, 2), 1)])
+                                          (16384, ("bits", 40, 6), 1), (256, ("bits", 250, 2), 1), (8192, ("bits", 64, 2), 1), (16384, ("bits", 64, 1), 1)])
 def test_ct_multiply_matches_oracle(eng, oracle, n, spec, batch):
     """FHEContext::multiply tensor product (src/fhe.cu:199-218)."""
     moduli = _moduli(spec, n)
@@ -170,7 +176,7 @@ def test_single_modulus_engine_reference_scenarios(eng, oracle):
     assert np.array_equal(dR.download(), p.schoolbook(a, b))
 
 
-@pytest.mark.parametrize("force,width", [("64", 2), ("256", 4)])
+@pytest.mark.parametrize("force,width", [("64", 2), ("65", 5), ("256", 4)])
 def test_forced_wider_paths_agree(eng, oracle, monkeypatch, force, width):
     """The same 40-bit basis through the 64-bit integer path and the full-width path (FHE_HIP_FORCE_WIDTH)."""
     n = 4096; moduli = nm.ntt_primes(40, n, 2); batch = 2
@@ -186,7 +192,7 @@ def test_forced_wider_paths_agree(eng, oracle, monkeypatch, force, width):
     assert np.array_equal(dA.download(a.shape), rp.forward(a, threads=8))
 
 
-@pytest.mark.parametrize("n,bits,L", [(8192, 30, 2), (8192, 43, 2), (16384, 40, 2), (8192, 62, 1), (2048, 30, 1)])
+@pytest.mark.parametrize("n,bits,L", [(8192, 30, 2), (8192, 43, 2), (16384, 40, 2), (8192, 62, 1), (2048, 30, 1), (8192, 64, 1), (2048, 63, 2), (16384, 64, 1)])
 def test_extreme_value_polynomials(eng, oracle, n, bits, L):
     """Worst-case magnitudes for the lazy / floating-point ranges: every coefficient q-1, alternating 0 / q-1,
     and q-1 against random (forward, inverse, fused multiply, tensor product)."""
@@ -320,7 +326,8 @@ def _random_keys(moduli, n, count, seed):
 
 @pytest.mark.parametrize("n,spec,w,batch", [(2048, [40961], 8, 2), (8192, ("bits", 30, 4), 16, 3), (4096, ("bits", 30, 2), 30, 2),
                                             (4096, ("bits", 40, 3), 20, 2), (2048, ("bits", 60, 2), 32, 1), (256, ("bits", 250, 2), 64, 2),
-                                            (1024, [12289], 16, 2)])
+                                            (1024, [12289], 16, 2), (2048, ("bits", 64, 2), 32, 2), (4096, ("bits", 63, 1), 16, 1),
+                                            (2048, ("mix", (64, 1), (62, 1)), 64, 1)])
 @pytest.mark.parametrize("single", [False, True])
 def test_relinearize_matches_oracle(eng, oracle, monkeypatch, n, spec, w, batch, single):
     """FHEContext::relinearize semantics (DESIGN.md, N1) on every width class, arbitrary key material; digit transforms two at a
@@ -345,7 +352,7 @@ def test_relinearize_matches_oracle(eng, oracle, monkeypatch, n, spec, w, batch,
         e.import_relin_keys(w, dkb[:-1], dka[:-1])
 
 
-@pytest.mark.parametrize("bits", [30, 40, 60])
+@pytest.mark.parametrize("bits", [30, 40, 60, 64])
 def test_relinearize_general_path_on_word_sized_moduli(eng, oracle, monkeypatch, bits):
     """The unfused composition (digit embedding, batched NTT, MAC) must agree with the fused key-switch kernels."""
     monkeypatch.setenv("FHE_HIP_NO_FUSED_KEYSWITCH", "1")
@@ -471,7 +478,7 @@ def test_repeated_calls_are_deterministic(eng):
 
 
 # ------------------------------------------------------------------------------------ RNS entry / exit (row a18)
-@pytest.mark.parametrize("n,bits,L", [(8192, 30, 4), (2048, 60, 4), (64, 120, 2), (1024, 30, 8), (256, 250, 1), (4096, 40, 6), (2048, 62, 3)])
+@pytest.mark.parametrize("n,bits,L", [(8192, 30, 4), (2048, 60, 4), (64, 120, 2), (1024, 30, 8), (256, 250, 1), (4096, 40, 6), (2048, 62, 3), (2048, 64, 3)])
 @pytest.mark.parametrize("word", [True, False])
 def test_to_rns_from_rns_match_oracle(eng, oracle, monkeypatch, n, bits, L, word):
     """word = True: to_rns on the integer word classes runs the streaming kernel on the field type; False: the 256-bit container kernel."""
@@ -513,7 +520,7 @@ def test_from_rns_rejects_oversized_basis(eng):
     e.to_rns(buf, out, 1)          # to_rns has no such limit
 
 
-@pytest.mark.parametrize("n,bits,L", [(8192, 30, 2), (4096, 40, 2), (2048, 60, 1), (256, 250, 1)])
+@pytest.mark.parametrize("n,bits,L", [(8192, 30, 2), (4096, 40, 2), (2048, 60, 1), (256, 250, 1), (2048, 64, 2)])
 def test_in_place_multiply_and_squaring(eng, oracle, n, bits, L):
     """Like the reference (which copies its operands, src/ntt.cu:50-58) the result may alias an operand."""
     moduli = nm.ntt_primes(bits, n, L)
@@ -529,7 +536,7 @@ def test_in_place_multiply_and_squaring(eng, oracle, n, bits, L):
     assert np.array_equal(dA.download(a.shape), sq)
 
 
-@pytest.mark.parametrize("n,bits,L,batch", [(2048, 30, 2, 19), (2048, 30, 3, 40), (2048, 40, 2, 21), (2048, 60, 1, 17)])
+@pytest.mark.parametrize("n,bits,L,batch", [(2048, 30, 2, 19), (2048, 30, 3, 40), (2048, 40, 2, 21), (2048, 60, 1, 17), (2048, 64, 1, 17)])
 def test_relinearize_xcd_mapped_batches(eng, oracle, n, bits, L, batch):
     """Batches large enough that the key-switch kernel's XCD-aware block -> (ciphertext, limb) map is in effect for most
     workgroups and the identity map for the tail (batch not a multiple of 8)."""
@@ -640,7 +647,7 @@ def test_largest_lds_size_tensor_and_keyswitch(eng, oracle):
     assert np.array_equal(c[0].download(a0.shape), r0) and np.array_equal(c[1].download(a0.shape), r1)
 
 
-@pytest.mark.parametrize("n,bits,L", [(8192, 30, 4), (2048, 60, 3), (64, 120, 2), (4096, 40, 6), (1024, 30, 2), (16384, 30, 6), (2048, 62, 2)])
+@pytest.mark.parametrize("n,bits,L", [(8192, 30, 4), (2048, 60, 3), (64, 120, 2), (4096, 40, 6), (1024, 30, 2), (16384, 30, 6), (2048, 62, 2), (2048, 64, 3)])
 @pytest.mark.parametrize("word", [True, False])
 def test_rescale_drop_last_matches_oracle(eng, oracle, monkeypatch, n, bits, L, word):
     """Modulus switching by dropping the last prime (rounded division), then the result is usable by an engine on L-1 primes.
@@ -664,7 +671,7 @@ def test_rescale_drop_last_matches_oracle(eng, oracle, monkeypatch, n, bits, L, 
 
 
 @pytest.mark.parametrize("n,bits,L,bits2,Lp", [(8192, 30, 4, 30, 5), (2048, 30, 3, 60, 2), (1024, 60, 2, 40, 3), (64, 120, 2, 250, 1), (4096, 40, 3, 40, 2),
-                                               (2048, 60, 2, 60, 3), (16384, 30, 6, 30, 2)])
+                                               (2048, 60, 2, 60, 3), (16384, 30, 6, 30, 2), (2048, 64, 2, 64, 3), (2048, 64, 2, 60, 2)])
 @pytest.mark.parametrize("word", [True, False])
 def test_fast_base_conversion_matches_oracle(eng, oracle, monkeypatch, n, bits, L, bits2, Lp, word):
     """word = True: same-class word-sized bases take the streaming kernel on the field type; mixed classes and word = False the 256-bit one."""
@@ -688,7 +695,7 @@ def test_fast_base_conversion_matches_oracle(eng, oracle, monkeypatch, n, bits, 
 
 # ------------------------------------------------------------------------------------ N3: blind-rotation inner loop
 @pytest.mark.parametrize("n,spec,w,batch", [(8192, ("bits", 30, 4), 16, 5), (4096, ("bits", 40, 2), 20, 3), (2048, ("bits", 60, 1), 32, 2),
-                                            (256, ("bits", 250, 1), 64, 2)])
+                                            (256, ("bits", 250, 1), 64, 2), (2048, ("bits", 64, 2), 32, 2)])
 def test_blind_rotate_step_matches_oracle(eng, oracle, n, spec, w, batch):
     moduli = _moduli(spec, n); L = len(moduli)
     e = eng.RnsNttEngine(n, moduli); rp = oracle.RnsPlan(n, moduli)
@@ -713,7 +720,7 @@ def test_blind_rotate_step_matches_oracle(eng, oracle, n, spec, w, batch):
 
 @pytest.mark.parametrize("n,spec,w,batch,steps", [(8192, ("bits", 30, 4), 16, 9, 3), (2048, ("bits", 30, 2), 30, 17, 2), (16384, ("bits", 30, 3), 16, 2, 1),
                                                   (32768, ("bits", 30, 2), 16, 2, 2), (4096, ("bits", 40, 2), 20, 3, 3), (2048, ("bits", 60, 2), 32, 2, 2),
-                                                  (256, ("bits", 250, 1), 64, 2, 2)])
+                                                  (256, ("bits", 250, 1), 64, 2, 2), (2048, ("bits", 64, 2), 32, 2, 3)])
 @pytest.mark.parametrize("fused", [True, False, "single"])
 def test_blind_rotate_loop_matches_oracle(eng, oracle, monkeypatch, n, spec, w, batch, steps, fused):
     """fhe_blind_rotate: `steps` external products with a different RGSW row set and different shifts per step; the fused
@@ -812,7 +819,7 @@ def test_literal_samplers_match_oracle(eng, oracle, q, seed, count):
 
 
 @pytest.mark.parametrize("n,spec,batch", [(8192, ("bits", 30, 4), 5), (4096, ("bits", 40, 3), 2), (2048, ("bits", 60, 2), 3), (256, ("bits", 250, 2), 2),
-                                          (1024, [12289], 3)])
+                                          (1024, [12289], 3), (2048, ("bits", 64, 2), 2)])
 def test_rns_samplers_match_oracle(eng, oracle, n, spec, batch):
     moduli = _moduli(spec, n); L = len(moduli)
     e = eng.RnsNttEngine(n, moduli); rp = oracle.RnsPlan(n, moduli)
@@ -1105,7 +1112,7 @@ def test_base_conversion_cache_survives_a_recycled_target_handle(eng, oracle):
 
 
 @pytest.mark.parametrize("n,spec,batch", [(8192, ("bits", 30, 4), 5), (4096, ("bits", 40, 2), 3), (2048, ("bits", 60, 2), 2), (16384, ("bits", 30, 2), 2),
-                                          (16384, ("bits", 40, 2), 1), (256, ("bits", 250, 1), 2)])
+                                          (16384, ("bits", 40, 2), 1), (256, ("bits", 250, 1), 2), (2048, ("bits", 64, 2), 2), (16384, ("bits", 64, 1), 1)])
 @pytest.mark.parametrize("square_kernels", [True, False])
 def test_squaring_forms_match_oracle(eng, oracle, monkeypatch, n, spec, batch, square_kernels):
     """multiply(a, a) and ct_multiply((a0, a1), (a0, a1)) take the squaring forms of the kernels (one load and one forward transform per
@@ -1129,7 +1136,7 @@ def test_squaring_forms_match_oracle(eng, oracle, monkeypatch, n, spec, batch, s
     assert np.array_equal(dA0.download(a0.shape), rp.polymul(a0, a0, threads=8))
 
 
-@pytest.mark.parametrize("n,spec,batch", [(8192, ("bits", 30, 4), 7), (4096, ("bits", 40, 2), 3), (2048, ("bits", 60, 2), 2), (256, ("bits", 250, 1), 3)])
+@pytest.mark.parametrize("n,spec,batch", [(8192, ("bits", 30, 4), 7), (4096, ("bits", 40, 2), 3), (2048, ("bits", 60, 2), 2), (256, ("bits", 250, 1), 3), (2048, ("bits", 64, 2), 2)])
 def test_multiply_by_one_shared_polynomial(eng, oracle, n, spec, batch):
     """fhe_rns_ntt_multiply_bcast: every element of a batch times ONE polynomial (a key, a plaintext); equals the element-wise products."""
     moduli = _moduli(spec, n)
