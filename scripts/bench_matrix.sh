@@ -4,7 +4,7 @@
 TAG=${1:-r01}
 OUT=gpurun_out/matrix_$TAG.jsonl
 : > $OUT
-run() { echo "== $*" >&2; timeout -k 10 600 python bench.py --no-cpu-baseline "$@" | grep '^{' >> $OUT || echo "FAILED: $*" >&2; }
+run() { echo "== $*" >&2; timeout -k 10 600 python bench.py --no-cpu-baseline --no-extras --no-verify "$@" | grep '^{' >> $OUT || echo "FAILED: $*" >&2; }
 # configs[1]: fused polymul, N = 8192, 4 x 30-bit limbs -- batch sweep
 run --steps 10 --warmup 2 --op multiply --batch 4096
 run --steps 10 --warmup 2 --op multiply --batch 1024
@@ -24,8 +24,20 @@ run --steps 5  --warmup 1 --op ctrelin  --batch 128 --n 16384 --limbs 6 --bits 4
 run --steps 10 --warmup 2 --op multiply --batch 1024 --bits 40 --limbs 3
 run --steps 10 --warmup 2 --op fwdinv   --batch 1024 --bits 40 --limbs 3
 run --steps 10 --warmup 2 --op multiply --batch 1024 --bits 60 --limbs 2
-run --steps 3  --warmup 1 --op multiply --batch 256 --bits 64 --limbs 2
-run --steps 3  --warmup 1 --op fwdinv   --batch 256 --bits 64 --limbs 2
+run --steps 10 --warmup 2 --op ct       --batch 1024 --bits 60 --limbs 2
+run --steps 5  --warmup 1 --op ctrelin  --batch 256 --bits 60 --limbs 2
+# 64-bit primes: full-range 64-bit class (FHE_WIDTH_64X)
+run --steps 10 --warmup 2 --op multiply --batch 1024 --bits 64 --limbs 2
+run --steps 10 --warmup 2 --op multiply --batch 256 --bits 64 --limbs 2
+run --steps 10 --warmup 2 --op fwdinv   --batch 1024 --bits 64 --limbs 2
+run --steps 10 --warmup 2 --op ct       --batch 1024 --bits 64 --limbs 2
+# full-width class (FHE_WIDTH_256): 128-bit and 250-bit primes, and the 64-bit primes forced onto it (the round-1 figure)
+run --steps 3  --warmup 1 --op multiply --batch 256 --bits 128 --limbs 2
+run --steps 3  --warmup 1 --op fwdinv   --batch 256 --bits 128 --limbs 2
+run --steps 3  --warmup 1 --op multiply --batch 128 --bits 250 --limbs 2
+run --steps 3  --warmup 1 --op fwdinv   --batch 128 --bits 250 --limbs 2
+FHE_HIP_FORCE_WIDTH=256 run --steps 3  --warmup 1 --op multiply --batch 256 --bits 64 --limbs 2
+FHE_HIP_FORCE_WIDTH=256 run --steps 3  --warmup 1 --op fwdinv   --batch 256 --bits 64 --limbs 2
 python - <<PY
 import json
 for l in open("$OUT"):
