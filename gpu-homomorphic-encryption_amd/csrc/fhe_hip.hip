@@ -15,6 +15,7 @@
 
 #include "host_math.hpp"
 #include "ntt256.hip.h"
+#include "ntt_wide.hip.h"
 #include "sampling.hip.h"
 #include "lds_launch.h"
 #include "ntt_lds.hip.h"
@@ -244,6 +245,11 @@ struct fhe_rns_ntt {
     int width = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
     void *d_limbs = nullptr;            // owned by d_tables
+    void *d_wlimbs = nullptr;           // FHE_WIDTH_256: WLimb<wide_nl>[L] for the NTT kernels of ntt_wide.hip.h (owned by d_tables)
+    int wide_nl = 0;                    // FHE_WIDTH_256: 64-bit limbs per residue in those kernels (2: q < 2^127, 4: q < 2^255)
+    bool wide_tiles = true;             // FHE_HIP_NO_WIDE_TILES=1: every stage as a global-memory pass (cross-check / A-B)
+    bool no_square = false, single_transforms = false, global_twiddles = false, check_inputs = false, no_fused_keyswitch = false,
+         no_word_conversions = false, no_fused_blind_rotate = false;   // environment switches, read once at creation
     std::vector<void *> d_tables;
     void *d_ws = nullptr; size_t ws_bytes = 0;
     uint32_t *d_flag = nullptr;
@@ -423,6 +429,31 @@ static int build_limbs256(fhe_rns_ntt *h, const std::vector<fhe_host::NttConstan
     return upload(h, limbs, &h->d_limbs);
 }
 
+// Constants of the LDS-staged wide kernels (ntt_wide.hip.h): Montgomery radix R = 2^(64 NL).
+template <int NL>
+static int build_wlimbs(fhe_rns_ntt *h, const std::vector<fhe_host::NttConstants> &cs) {
+    using W = fhe_dev::wint<NL>;
+    std::vector<fhe_dev::WLimb<NL>> limbs(h->L);
+    for (uint32_t l = 0; l < h->L; l++) {
+        const fhe_host::NttConstants &c = cs[l];
+        fhe_host::Mod M(c.q);
+        U256 Rn = M.r1;                                   // 2^256 mod q
+        if (NL == 2) { U256 t; t.w[2] = 1; Rn = M.reduce(t); }   // 2^128 mod q
+        auto put = [](W &dst, const U256 &v) { for (int i = 0; i < NL; i++) dst.l[i] = v.w[i]; };
+        std::vector<W> tw(h->n), itw(h->n);
+        for (uint32_t k = 0; k < h->n; k++) { put(tw[k], M.mul(c.tw[k], Rn)); put(itw[k], M.mul(c.itw[k], Rn)); }
+        fhe_dev::WLimb<NL> &P = limbs[l];
+        std::memset(&P, 0, sizeof(P));
+        const U256 R2 = M.mul(Rn, Rn), nR = M.mul(c.n_inv, Rn);
+        put(P.q, c.q); put(P.ninv_m, nR); put(P.ninv_r2, M.mul(nR, Rn)); put(P.r2, R2);
+        P.qinv32 = (uint32_t)M.inv0;
+        void *d = nullptr; int rc;
+        if ((rc = upload(h, tw, &d))) return rc; P.tw = (const W *)d;
+        if ((rc = upload(h, itw, &d))) return rc; P.itw = (const W *)d;
+    }
+    return upload(h, limbs, &h->d_wlimbs);
+}
+
 // base_only: an RNS base without a ring (RNSContext, include/rns.cuh:27-66): the handle is an engine of degree n = 1, whose
 // buffers [batch][L][1] are exactly RNSContext's interleaved [count][num_primes] layout (src/rns.cu:103-104) and whose
 // transforms are the identity (Z_q[x]/(x + 1) = Z_q), so every container-level entry point works on it unchanged.
@@ -462,7 +493,7 @@ static int create_impl(fhe_rns_ntt **out, uint32_t n, const uint64_t (*moduli)[4
     const bool lds_size = h->log_n >= 11 && h->log_n <= 15;
     const char *force = getenv("FHE_HIP_FORCE_WIDTH");       // testing aid: "52" / "64" / "256" force a wider path than needed
     const int floor_w = force ? atoi(force) : 0;
-    if (floor_w >= 256) h->width = FHE_WIDTH_256;
+    if (floor_w >= 128) h->width = FHE_WIDTH_256;      // 128: the full-width class on two 64-bit limbs (needs q < 2^127), 256: on four
     else if (lds_size && max_bits <= 30 && floor_w < 52) h->width = FHE_WIDTH_32;
     else if (lds_size && h->log_n <= 14 && max_bits <= 43 && floor_w < 64) h->width = FHE_WIDTH_52;
     else if (lds_size && h->log_n <= 14 && max_bits <= 62 && floor_w < 65) h->width = FHE_WIDTH_64;
@@ -478,7 +509,19 @@ static int create_impl(fhe_rns_ntt **out, uint32_t n, const uint64_t (*moduli)[4
 #undef TRY_OR_DESTROY
     rc = h->width == FHE_WIDTH_32 ? build_limbs32(h, cs) : h->width == FHE_WIDTH_52 ? build_limbs52(h, cs)
          : h->width == FHE_WIDTH_64 ? build_limbs64(h, cs) : h->width == FHE_WIDTH_64X ? build_limbs64x(h, cs) : build_limbs256(h, cs);
+    if (!rc && h->width == FHE_WIDTH_256) {
+        h->wide_nl = (max_bits <= 127 && floor_w != 256) ? 2 : 4;
+        rc = h->wide_nl == 2 ? build_wlimbs<2>(h, cs) : build_wlimbs<4>(h, cs);
+    }
     if (rc) { destroy_impl(h); return rc; }
+    h->wide_tiles = !getenv("FHE_HIP_NO_WIDE_TILES");
+    h->no_square = getenv("FHE_HIP_NO_SQUARE_KERNELS") != nullptr;
+    h->single_transforms = getenv("FHE_HIP_NO_PAIRED_TRANSFORMS") != nullptr;
+    h->global_twiddles = getenv("FHE_HIP_NO_LDS_TWIDDLES") != nullptr;
+    h->no_fused_keyswitch = getenv("FHE_HIP_NO_FUSED_KEYSWITCH") != nullptr;
+    h->no_word_conversions = getenv("FHE_HIP_NO_WORD_CONVERSIONS") != nullptr;
+    h->no_fused_blind_rotate = getenv("FHE_HIP_NO_FUSED_BLIND_ROTATE") != nullptr;
+    { const char *e = getenv("FHE_HIP_CHECK_INPUTS"); h->check_inputs = e && e[0] == '1'; }
     *out = h;
     return FHE_OK;
 }
@@ -502,30 +545,86 @@ static int ensure_ws(fhe_rns_ntt *h, size_t bytes) {
 }
 
 // ---- general (256-bit) path launchers -----------------------------------------------------------------
-static int run256_transform(fhe_rns_ntt *h, fhe_dev::u256 *data, uint32_t polys, bool forward) {
-    const uint32_t chunk_max = (65535u / h->L) * h->L;
-    const fhe_dev::Limb256 *limbs = (const fhe_dev::Limb256 *)h->d_limbs;
+// One radix-2^R global-memory pass over `polys` polynomials (src -> dst).  forward: stages s0 .. s0+R-1; inverse: index bits s0 .. s0+R-1.
+template <int NL, bool FWD>
+static void wide_pass(fhe_rns_ntt *h, fhe_dev::u256 *dst, const fhe_dev::u256 *src, uint32_t polys, uint32_t s0, uint32_t R, uint32_t scale) {
+    const uint32_t chunk_max = (65535u / h->L) * h->L;      // grid.y limit; chunks keep the limb phase (polynomial index mod L)
+    const fhe_dev::WLimb<NL> *limbs = (const fhe_dev::WLimb<NL> *)h->d_wlimbs;
     for (uint32_t done = 0; done < polys;) {
-        uint32_t chunk = polys - done < chunk_max ? polys - done : chunk_max;
-        fhe_dev::u256 *d = data + (size_t)done * h->n;
-        for (uint32_t s = 0; s < h->log_n;) {
-            uint32_t R = h->log_n - s >= 3 ? 3 : h->log_n - s;   // radix-8 passes (128 VGPRs, no scratch with the hand-scheduled product)
-            dim3 grid(((h->n >> R) + 255) / 256, chunk), block(256);
-            if (forward) {
-                if (R == 3) hipLaunchKernelGGL(fhe_dev::ntt256_fwd_pass<3>, grid, block, 0, h->stream, d, limbs, h->L, h->log_n, s);
-                else if (R == 2) hipLaunchKernelGGL(fhe_dev::ntt256_fwd_pass<2>, grid, block, 0, h->stream, d, limbs, h->L, h->log_n, s);
-                else hipLaunchKernelGGL(fhe_dev::ntt256_fwd_pass<1>, grid, block, 0, h->stream, d, limbs, h->L, h->log_n, s);
-            } else {
-                if (R == 3) hipLaunchKernelGGL(fhe_dev::ntt256_inv_pass<3>, grid, block, 0, h->stream, d, limbs, h->L, h->log_n, s);
-                else if (R == 2) hipLaunchKernelGGL(fhe_dev::ntt256_inv_pass<2>, grid, block, 0, h->stream, d, limbs, h->L, h->log_n, s);
-                else hipLaunchKernelGGL(fhe_dev::ntt256_inv_pass<1>, grid, block, 0, h->stream, d, limbs, h->L, h->log_n, s);
-            }
-            s += R;
-        }
+        const uint32_t chunk = polys - done < chunk_max ? polys - done : chunk_max;
+        fhe_dev::u256 *d = dst + (size_t)done * h->n; const fhe_dev::u256 *sp = src + (size_t)done * h->n;
+        dim3 grid(((h->n >> R) + 255) / 256, chunk), block(256);
+        if (R == 3) hipLaunchKernelGGL((fhe_dev::wide_pass_kernel<NL, 3, FWD>), grid, block, 0, h->stream, d, sp, limbs, h->L, h->log_n, s0, scale);
+        else if (R == 2) hipLaunchKernelGGL((fhe_dev::wide_pass_kernel<NL, 2, FWD>), grid, block, 0, h->stream, d, sp, limbs, h->L, h->log_n, s0, scale);
+        else hipLaunchKernelGGL((fhe_dev::wide_pass_kernel<NL, 1, FWD>), grid, block, 0, h->stream, d, sp, limbs, h->L, h->log_n, s0, scale);
         done += chunk;
     }
-    return post_launch(h->stream, forward ? "ntt256 forward" : "ntt256 inverse");
 }
+template <int NL, int MODE>
+static void wide_tile(fhe_rns_ntt *h, fhe_dev::u256 *dst, const fhe_dev::u256 *src, const fhe_dev::u256 *src2, uint32_t polys, uint32_t scale) {
+    const uint32_t tiles_log = h->log_n - fhe_dev::WT_LOG;
+    const uint32_t chunk_max = (0x7fffffffu >> tiles_log) / h->L * h->L;
+    for (uint32_t done = 0; done < polys;) {
+        const uint32_t chunk = polys - done < chunk_max ? polys - done : chunk_max;
+        const size_t o = (size_t)done * h->n;
+        hipLaunchKernelGGL((fhe_dev::wide_tile_kernel<NL, MODE>), dim3(chunk << tiles_log), dim3(fhe_dev::WT_T), 0, h->stream, dst + o, src + o,
+                           src2 ? src2 + o : nullptr, (const fhe_dev::WLimb<NL> *)h->d_wlimbs, h->L, h->log_n, scale);
+        done += chunk;
+    }
+}
+// Number of leading (forward) / trailing (inverse) stages that run as global passes: everything above the 2^11-coefficient LDS tile.
+static uint32_t wide_top_stages(const fhe_rns_ntt *h) {
+    return (h->wide_tiles && h->log_n >= (uint32_t)fhe_dev::WT_LOG) ? h->log_n - fhe_dev::WT_LOG : h->log_n;
+}
+// The top stages of a forward transform, src -> dst (src == dst allowed): R <= 3 stages per launch.
+template <int NL>
+static void wide_forward_top(fhe_rns_ntt *h, fhe_dev::u256 *dst, const fhe_dev::u256 *src, uint32_t polys) {
+    const uint32_t top = wide_top_stages(h);
+    for (uint32_t s = 0; s < top;) {
+        const uint32_t R = top - s >= 3 ? 3 : top - s;
+        wide_pass<NL, true>(h, dst, s ? dst : src, polys, s, R, 0);
+        s += R;
+    }
+}
+// The trailing stages of an inverse transform, in place on data, with the final scaling (1: n^-1, 2: n^-1 R for the fused products).
+template <int NL>
+static void wide_inverse_top(fhe_rns_ntt *h, fhe_dev::u256 *data, uint32_t polys, uint32_t scale) {
+    const uint32_t top = wide_top_stages(h), b_first = h->log_n - top;
+    if (!h->log_n && scale) {                               // degree-1 engine: no butterflies, only the scaling (n^-1 = 1)
+        const size_t count = (size_t)polys;
+        hipLaunchKernelGGL((fhe_dev::wide_scale_kernel<NL>), dim3(ew_grid(count)), dim3(256), 0, h->stream, data, data,
+                           (const fhe_dev::WLimb<NL> *)h->d_wlimbs, h->L, 0u, scale, count);
+    }
+    for (uint32_t s = 0; s < top;) {
+        const uint32_t R = top - s >= 3 ? 3 : top - s;
+        wide_pass<NL, false>(h, data, data, polys, b_first + s, R, s + R == top ? scale : 0);
+        s += R;
+    }
+}
+template <int NL>
+static int wide_transform_t(fhe_rns_ntt *h, fhe_dev::u256 *dst, const fhe_dev::u256 *src, uint32_t polys, bool forward, uint32_t scale) {
+    const uint32_t top = wide_top_stages(h);
+    const bool tiled = top < h->log_n;
+    if (!h->log_n) {                                        // degree 1: the transforms are the identity (stand-alone inverse: n^-1 = 1)
+        if (dst != src) HIP_TRY(hipMemcpyAsync(dst, src, (size_t)polys * 32, hipMemcpyDeviceToDevice, h->stream));
+        if (!forward && scale == 2) wide_inverse_top<NL>(h, dst, polys, 2);
+        return post_launch(h->stream, "wide identity");
+    }
+    if (forward) {
+        wide_forward_top<NL>(h, dst, src, polys);
+        if (tiled) wide_tile<NL, fhe_dev::TILE_FWD>(h, dst, top ? dst : src, nullptr, polys, 0);
+    } else {
+        if (tiled) wide_tile<NL, fhe_dev::TILE_INV>(h, dst, src, nullptr, polys, top ? 0 : scale);
+        else if (dst != src) HIP_TRY(hipMemcpyAsync(dst, src, (size_t)polys * h->n * 32, hipMemcpyDeviceToDevice, h->stream));
+        wide_inverse_top<NL>(h, dst, polys, scale);
+    }
+    return post_launch(h->stream, forward ? "wide forward" : "wide inverse");
+}
+// src -> dst (in place when equal); inverse: scale 1 = n^-1 (stand-alone), 2 = n^-1 R (inputs carry the R^-1 of a fused pointwise product)
+static int run256_transform(fhe_rns_ntt *h, fhe_dev::u256 *dst, const fhe_dev::u256 *src, uint32_t polys, bool forward, uint32_t scale = 1) {
+    return h->wide_nl == 2 ? wide_transform_t<2>(h, dst, src, polys, forward, scale) : wide_transform_t<4>(h, dst, src, polys, forward, scale);
+}
+static int run256_transform(fhe_rns_ntt *h, fhe_dev::u256 *data, uint32_t polys, bool forward) { return run256_transform(h, data, data, polys, forward, 1); }
 
 template <int OP>
 static int run256_ew(fhe_rns_ntt *h, void *r, const void *a, const void *b, uint32_t polys, const char *what) {
@@ -544,9 +643,9 @@ static int lds_run(fhe_rns_ntt *h, int op, void *r0, void *r1, void *r2, const v
     fhe_dev::lds_launch_fn fn = fhe_dev::lds_lookup(lds_width_id(h), (int)h->log_n);
     if (!fn) return fail(FHE_ERR_UNSUPPORTED, "transform size outside the LDS-resident range");
     fhe_dev::LdsArgs A{op, r0, r1, r2, a0, a1, b0, b1, h->d_limbs, h->L, polys, h->stream};
-    A.single_transforms = getenv("FHE_HIP_NO_PAIRED_TRANSFORMS") != nullptr;
+    A.single_transforms = h->single_transforms;
     A.b_polys = b_polys;
-    A.square = !b_polys && !getenv("FHE_HIP_NO_SQUARE_KERNELS") &&
+    A.square = !b_polys && !h->no_square &&
                ((op == fhe_dev::LDS_MULTIPLY && a0 == b0) || (op == fhe_dev::LDS_CT_MULTIPLY && a0 == b0 && a1 == b1));
     fn(A);
     return post_launch(h->stream, what);
@@ -589,43 +688,66 @@ static int do_ew(fhe_rns_ntt *h, void *r, const void *a, const void *b, uint32_t
     if (h->width == FHE_WIDTH_64X) return lds_ew<fhe_dev::F64X, OP>(h, r, a, b, polys, what);
     return run256_ew<OP>(h, r, a, b, polys, what);
 }
+// Full-width multiply without operand copies (the reference copies both operands first, src/ntt.cu:50-58): the top forward stages
+// write the transformed operands into the workspace, one fused tile launch does the remaining forward stages of both operands, the
+// pointwise product and the low inverse stages, the trailing inverse stages finish in place on the result.
+template <int NL>
+static int wide_multiply_t(fhe_rns_ntt *h, void *d_r, const void *d_a, const void *d_b, uint32_t polys) {
+    using fhe_dev::u256;
+    const uint32_t top = wide_top_stages(h);
+    const bool tiled = top < h->log_n;
+    const size_t bytes = (size_t)polys * h->n * 32;
+    const u256 *A = (const u256 *)d_a, *B = (const u256 *)d_b;
+    if (!h->log_n) return run256_ew<0>(h, d_r, d_a, d_b, polys, "pointwise");     // degree 1: the product in Z_q
+    if (top) {
+        int rc = ensure_ws(h, 2 * bytes); if (rc) return rc;
+        u256 *wa = (u256 *)h->d_ws, *wb = (u256 *)((char *)h->d_ws + bytes);
+        wide_forward_top<NL>(h, wa, A, polys);
+        if (d_b != d_a) wide_forward_top<NL>(h, wb, B, polys);
+        B = d_b != d_a ? wb : wa; A = wa;
+    }
+    if (tiled) {
+        wide_tile<NL, fhe_dev::TILE_MUL>(h, (u256 *)d_r, A, B, polys, top ? 0 : 2);
+    } else {                                                // n < 2^11 (or FHE_HIP_NO_WIDE_TILES): pointwise product of the transformed copies
+        const size_t count = (size_t)polys * h->n;
+        hipLaunchKernelGGL((fhe_dev::wide_pointwise_kernel<NL>), dim3(ew_grid(count)), dim3(256), 0, h->stream, (u256 *)d_r, A, B,
+                           (const fhe_dev::WLimb<NL> *)h->d_wlimbs, h->L, h->log_n, count);
+    }
+    wide_inverse_top<NL>(h, (u256 *)d_r, polys, 2);
+    return post_launch(h->stream, "wide multiply");
+}
+template <int NL>
+static int wide_ct_multiply_t(fhe_rns_ntt *h, void *c0, void *c1, void *c2, const void *a0, const void *a1, const void *b0, const void *b1, uint32_t polys) {
+    using fhe_dev::u256;
+    // 4 forward transforms into the workspace (no copies), one pass for the three NTT-domain products, 3 inverse transforms
+    const size_t bytes = (size_t)polys * h->n * 32;
+    int rc = ensure_ws(h, 4 * bytes); if (rc) return rc;
+    char *ws = (char *)h->d_ws;
+    const void *src[4] = {a0, a1, b0, b1};
+    for (int i = 0; i < 4; i++)
+        if ((rc = run256_transform(h, (u256 *)(ws + i * bytes), (const u256 *)src[i], polys, true, 0))) return rc;
+    const size_t count = (size_t)polys * h->n;
+    hipLaunchKernelGGL((fhe_dev::wide_ct_pointwise_kernel<NL>), dim3(ew_grid(count)), dim3(256), 0, h->stream, (u256 *)c0, (u256 *)c1, (u256 *)c2,
+                       (const u256 *)ws, (const u256 *)(ws + bytes), (const u256 *)(ws + 2 * bytes), (const u256 *)(ws + 3 * bytes),
+                       (const fhe_dev::WLimb<NL> *)h->d_wlimbs, h->L, h->log_n, count);
+    for (void *c : {c0, c1, c2})
+        if ((rc = run256_transform(h, (u256 *)c, (const u256 *)c, polys, false, 2))) return rc;
+    return FHE_OK;
+}
 static int do_multiply(fhe_rns_ntt *h, void *d_r, const void *d_a, const void *d_b, uint32_t batch) {
     const uint32_t polys = batch * h->L;
     // d_r may alias d_a and/or d_b, as in the reference (which copies its operands first, src/ntt.cu:50-58): every
     // workgroup loads both of its operand polynomials completely before its first store, and the general path works on copies.
     if (h->width != FHE_WIDTH_256)
         return lds_run(h, fhe_dev::LDS_MULTIPLY, d_r, nullptr, nullptr, d_a, nullptr, d_b, nullptr, polys, "ntt_multiply_kernel");
-    // general path: copies keep the operands intact (src/ntt.cu:50-58), one batched forward over both
-    const size_t bytes = (size_t)polys * h->n * 32;
-    int rc = ensure_ws(h, 2 * bytes); if (rc) return rc;
-    char *ws = (char *)h->d_ws;
-    HIP_TRY(hipMemcpyAsync(ws, d_a, bytes, hipMemcpyDeviceToDevice, h->stream));
-    HIP_TRY(hipMemcpyAsync(ws + bytes, d_b, bytes, hipMemcpyDeviceToDevice, h->stream));
-    if ((rc = run256_transform(h, (fhe_dev::u256 *)ws, 2 * polys, true))) return rc;
-    if ((rc = run256_ew<0>(h, d_r, ws, ws + bytes, polys, "ntt256 pointwise"))) return rc;
-    return run256_transform(h, (fhe_dev::u256 *)d_r, polys, false);
+    return h->wide_nl == 2 ? wide_multiply_t<2>(h, d_r, d_a, d_b, polys) : wide_multiply_t<4>(h, d_r, d_a, d_b, polys);
 }
 static int do_ct_multiply(fhe_rns_ntt *h, void *c0, void *c1, void *c2, const void *a0, const void *a1, const void *b0,
                           const void *b1, uint32_t batch) {
     const uint32_t polys = batch * h->L;
     if (h->width != FHE_WIDTH_256)
         return lds_run(h, fhe_dev::LDS_CT_MULTIPLY, c0, c1, c2, a0, a1, b0, b1, polys, "ntt_ct_multiply_kernel");
-    // general path: 4 forward, 4 products + 1 add in the NTT domain, 3 inverse
-    const size_t bytes = (size_t)polys * h->n * 32;
-    int rc = ensure_ws(h, 5 * bytes); if (rc) return rc;
-    char *ws = (char *)h->d_ws;
-    const void *src[4] = {a0, a1, b0, b1};
-    for (int i = 0; i < 4; i++) HIP_TRY(hipMemcpyAsync(ws + i * bytes, src[i], bytes, hipMemcpyDeviceToDevice, h->stream));
-    if ((rc = run256_transform(h, (fhe_dev::u256 *)ws, 4 * polys, true))) return rc;
-    char *A0 = ws, *A1 = ws + bytes, *B0 = ws + 2 * bytes, *B1 = ws + 3 * bytes, *T = ws + 4 * bytes;
-    if ((rc = run256_ew<0>(h, c0, A0, B0, polys, "ct pointwise"))) return rc;
-    if ((rc = run256_ew<0>(h, c1, A0, B1, polys, "ct pointwise"))) return rc;
-    if ((rc = run256_ew<0>(h, T, A1, B0, polys, "ct pointwise"))) return rc;
-    if ((rc = run256_ew<1>(h, c1, c1, T, polys, "ct add"))) return rc;
-    if ((rc = run256_ew<0>(h, c2, A1, B1, polys, "ct pointwise"))) return rc;
-    if ((rc = run256_transform(h, (fhe_dev::u256 *)c0, polys, false))) return rc;
-    if ((rc = run256_transform(h, (fhe_dev::u256 *)c1, polys, false))) return rc;
-    return run256_transform(h, (fhe_dev::u256 *)c2, polys, false);
+    return h->wide_nl == 2 ? wide_ct_multiply_t<2>(h, c0, c1, c2, a0, a1, b0, b1, polys) : wide_ct_multiply_t<4>(h, c0, c1, c2, a0, a1, b0, b1, polys);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -814,7 +936,7 @@ extern "C" int fhe_relin_keys_create(fhe_rns_ntt_t *h, fhe_relin_keys_t **out, u
         for (const U256 &q : h->moduli) { fhe_host::u128 v = q.w[0]; q_min = v < q_min ? v : q_min; q_max = v > q_max ? v : q_max; }
         digits_fit = (decomp_bits >= 64 ? q_max : (((fhe_host::u128)1 << decomp_bits) < q_max ? ((fhe_host::u128)1 << decomp_bits) : q_max)) <= q_min;
     }
-    if (!rc && h->width != FHE_WIDTH_256 && digits_fit && !getenv("FHE_HIP_NO_FUSED_KEYSWITCH")) {
+    if (!rc && h->width != FHE_WIDTH_256 && digits_fit && !h->no_fused_keyswitch) {
         rc = pack_relin_keys(h, rk);
         if (!rc) {   // the fused kernels read only the packed tables (n * sizeof(E) bytes per key polynomial instead of n * 32): drop the
                      // container copy, so that a bootstrapping key of several hundred RGSW ciphertexts fits (hipFree waits for the packing)
@@ -871,8 +993,8 @@ extern "C" int fhe_ct_relinearize(fhe_rns_ntt_t *h, const fhe_relin_keys_t *rk, 
         if (!fn) return fail(FHE_ERR_UNSUPPORTED, "transform size outside the LDS-resident range");
         fhe_dev::LdsArgs A{fhe_dev::LDS_KEYSWITCH, d_c0, d_c1, nullptr, d_c2, nullptr, nullptr, nullptr, h->d_limbs, h->L, batch * h->L, h->stream};
         A.kb = rk->d_pkb; A.ka = rk->d_pka; A.K = rk->K; A.w = rk->decomp_bits;
-        A.global_twiddles = getenv("FHE_HIP_NO_LDS_TWIDDLES") != nullptr;
-    A.single_transforms = getenv("FHE_HIP_NO_PAIRED_TRANSFORMS") != nullptr;
+        A.global_twiddles = h->global_twiddles;
+    A.single_transforms = h->single_transforms;
         fn(A);
         return post_launch(h->stream, "ntt_keyswitch_kernel");
     }
@@ -984,7 +1106,7 @@ static int to_rns_word(fhe_rns_ntt *h, void *d_rns, const void *d_values, uint32
 extern "C" int fhe_rns_to_rns(fhe_rns_ntt_t *h, void *d_rns, const void *d_values, uint32_t batch) {
     int rc = check_call(h, batch, "to_rns"); if (rc) return rc;
     if (!d_rns || !d_values || d_rns == d_values) return fail(FHE_ERR_INVALID_ARG, "to_rns: null or aliased argument");
-    if (!getenv("FHE_HIP_NO_WORD_CONVERSIONS")) {       // word-sized classes: a streaming kernel on the field type
+    if (!h->no_word_conversions) {       // word-sized classes: a streaming kernel on the field type
         if (h->width == FHE_WIDTH_32) return to_rns_word<fhe_dev::F32, uint32_t>(h, d_rns, d_values, batch);
         if (h->width == FHE_WIDTH_52) return to_rns_word<fhe_dev::F52, uint32_t>(h, d_rns, d_values, batch);
         if (h->width == FHE_WIDTH_64) return to_rns_word<fhe_dev::F64, uint64_t>(h, d_rns, d_values, batch);
@@ -1023,7 +1145,7 @@ extern "C" int fhe_rns_from_rns(fhe_rns_ntt_t *h, void *d_values, const void *d_
     if (!d_rns || !d_values || d_rns == d_values) return fail(FHE_ERR_INVALID_ARG, "from_rns: null or aliased argument");
     if ((rc = ensure_crt(h))) return rc;
     if (h->crt_state < 0) return fail(FHE_ERR_UNSUPPORTED, "from_rns: the product of the moduli must be below 2^255 to fit a 256-bit container");
-    if (!getenv("FHE_HIP_NO_WORD_CONVERSIONS")) {       // word-sized classes: word x 256-bit accumulation instead of 256-bit Montgomery products
+    if (!h->no_word_conversions) {       // word-sized classes: word x 256-bit accumulation instead of 256-bit Montgomery products
         if (h->width == FHE_WIDTH_32) return from_rns_word<fhe_dev::F32>(h, d_values, d_rns, batch);
         if (h->width == FHE_WIDTH_52) return from_rns_word<fhe_dev::F52>(h, d_values, d_rns, batch);
         if (h->width == FHE_WIDTH_64) return from_rns_word<fhe_dev::F64>(h, d_values, d_rns, batch);
@@ -1083,7 +1205,7 @@ extern "C" int fhe_rns_rescale_drop_last(fhe_rns_ntt_t *h, void *d_out, const vo
     int rc = check_call(h, batch, "rescale_drop_last"); if (rc) return rc;
     if (!d_out || !d_in || d_out == d_in) return fail(FHE_ERR_INVALID_ARG, "rescale_drop_last: null or aliased argument");
     if (h->L < 2) return fail(FHE_ERR_INVALID_ARG, "rescale_drop_last: needs at least two primes");
-    if (!getenv("FHE_HIP_NO_WORD_CONVERSIONS")) {       // word-sized classes: streaming kernels on the field type
+    if (!h->no_word_conversions) {       // word-sized classes: streaming kernels on the field type
         if (h->width == FHE_WIDTH_32) return rescale_word<fhe_dev::F32>(h, d_out, d_in, batch);
         if (h->width == FHE_WIDTH_52) return rescale_word<fhe_dev::F52>(h, d_out, d_in, batch);
         if (h->width == FHE_WIDTH_64) return rescale_word<fhe_dev::F64>(h, d_out, d_in, batch);
@@ -1112,7 +1234,7 @@ extern "C" int fhe_rns_fast_base_convert(fhe_rns_ntt_t *h, fhe_rns_ntt_t *target
     int rc = check_call(h, batch, "fast_base_convert"); if (rc) return rc;
     if (!target || !d_out || !d_in || d_out == d_in) return fail(FHE_ERR_INVALID_ARG, "fast_base_convert: null or aliased argument");
     if (target->n != h->n) return fail(FHE_ERR_INVALID_ARG, "fast_base_convert: source and target engines differ in degree");
-    if (h->width == target->width && h->width != FHE_WIDTH_256 && !getenv("FHE_HIP_NO_WORD_CONVERSIONS")) {
+    if (h->width == target->width && h->width != FHE_WIDTH_256 && !h->no_word_conversions) {
         if (h->width == FHE_WIDTH_32) return base_convert_word<fhe_dev::F32>(h, target, d_out, d_in, batch);
         if (h->width == FHE_WIDTH_52) return base_convert_word<fhe_dev::F52>(h, target, d_out, d_in, batch);
         if (h->width == FHE_WIDTH_64X) return base_convert_word<fhe_dev::F64X>(h, target, d_out, d_in, batch);
@@ -1179,8 +1301,8 @@ static int blind_rotate_step_fused(fhe_rns_ntt_t *h, const fhe_relin_keys_t *r0,
     if (!fn) return fail(FHE_ERR_UNSUPPORTED, "transform size outside the LDS-resident range");
     fhe_dev::LdsArgs A{fhe_dev::LDS_EXTPROD, out0, out1, nullptr, in0, in1, nullptr, nullptr, h->d_limbs, h->L, batch * h->L, h->stream};
     A.kb = r0->d_pkb; A.ka = r0->d_pka; A.kb1 = r1->d_pkb; A.ka1 = r1->d_pka; A.K = r0->K; A.w = r0->decomp_bits; A.shifts = d_shifts;
-    A.global_twiddles = getenv("FHE_HIP_NO_LDS_TWIDDLES") != nullptr;
-    A.single_transforms = getenv("FHE_HIP_NO_PAIRED_TRANSFORMS") != nullptr;
+    A.global_twiddles = h->global_twiddles;
+    A.single_transforms = h->single_transforms;
     fn(A);
     return post_launch(h->stream, "ntt_extprod_kernel");
 }
@@ -1199,7 +1321,7 @@ extern "C" int fhe_blind_rotate(fhe_rns_ntt_t *h, const fhe_relin_keys_t *const 
         for (int x = 0; x < 4; x++) for (int y = x + 1; y < 4; y++)
             if (bufs[x] == bufs[y]) return fail(FHE_ERR_INVALID_ARG, "blind_rotate: accumulators and scratch must be distinct buffers");
     }
-    bool fused = h->width != FHE_WIDTH_256 && !getenv("FHE_HIP_NO_FUSED_BLIND_ROTATE");
+    bool fused = h->width != FHE_WIDTH_256 && !h->no_fused_blind_rotate;
     for (uint32_t s = 0; s < steps; s++) {
         if ((rc = check_rows(h, rows_c0[s], rows_c1[s]))) return rc;
         fused = fused && rows_c0[s]->d_pkb && rows_c1[s]->d_pkb;

@@ -1,0 +1,400 @@
+// ntt_wide.hip.h -- LDS-staged negacyclic NTT / polymul kernels for moduli wider than one machine word (FHE_WIDTH_256).
+//
+// Replaces ntt_forward_optimized_kernel / ntt_inverse_optimized_kernel / ntt_pointwise_mul_kernel (kernels/ntt_kernels.cu:7-137:
+// shared-memory staging of 32-byte elements, one butterfly stage per barrier) and the multi-limb Montgomery product built on the
+// PTX carry chains (include/bigint.cuh:76-140, kernels/ptx_bigint.cuh:34-117) for q up to 2^255.
+//
+//   * NL = number of 64-bit limbs the modulus needs: 2 (q < 2^127) or 4 (q < 2^255).  The Montgomery radix is R = 2^(64 NL);
+//     twiddles are stored as w * R mod q, so mont(x, w R) on plain-form data is the exact product and every value stays the
+//     canonical residue the reference's R = 2^256 primitives would produce (upper container words zero for NL = 2).
+//   * Tile = 2^11 consecutive coefficients, one workgroup of 256 threads, 8 coefficients per thread (64 data VGPRs at NL = 4).
+//     Eleven butterfly stages run per HBM round trip: three register groups of 3 stages + one of 2, exchanged through LDS.
+//     The LDS image is limb-planar (plane w holds 32-bit word w of every coefficient) and XOR-swizzled so that all four
+//     exchange patterns are bank-conflict-free for the 32-lane groups of ds_read_b32 / ds_write_b32 (see swz()).
+//   * N = 2^11: one launch per transform, HBM traffic 2 S.  N > 2^11: the top log2(N) - 11 stages run first (forward) / last
+//     (inverse) as a register-only radix-2^R pass over global memory (wide_pass_kernel, R <= 3 per launch), so N = 8192 costs
+//     4 S per transform instead of the 10 S of five un-staged passes.
+//   * Fused multiply (wide_tile_kernel<NL, TILE_MUL>): forward(a tile), forward(b tile), pointwise Montgomery product, inverse
+//     stages, one store -- no operand copies, no NTT-domain round trip: 3 S at N = 2^11, 9 S at N = 8192 (was 37 S).
+//   * The Montgomery product is finely integrated product scanning over 32-bit words on v_mad_u64_u32 with the carry-outs in
+//     SGPR pairs (mac1 / mac2 / mac3 in u256_dev.h): 2 NW^2 + NW multiplies for NW = 2 NL words.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "u256_dev.h"
+
+namespace fhe_dev {
+
+template <int NL> struct wint { uint64_t l[NL]; };
+
+// Per-limb constants of the wide NTT kernels (device memory, one entry per RNS prime).
+template <int NL>
+struct WLimb {
+    wint<NL> q;
+    wint<NL> ninv_m;      // n^-1 * R mod q        (stand-alone inverse)
+    wint<NL> ninv_r2;     // n^-1 * R^2 mod q      (fused multiply: absorbs the R^-1 of the pointwise product)
+    wint<NL> r2;          // R^2 mod q
+    uint32_t qinv32, _pad[3];   // -q^-1 mod 2^32
+    const wint<NL> *tw;   // [n] psi^bitrev(k) * R mod q
+    const wint<NL> *itw;  // [n] psi^-bitrev(k) * R mod q
+};
+
+template <int NL> __device__ __forceinline__ wint<NL> wadd(const wint<NL> &a, const wint<NL> &b) {
+    wint<NL> r; u128_t c = 0;
+#pragma unroll
+    for (int i = 0; i < NL; i++) { c += (u128_t)a.l[i] + b.l[i]; r.l[i] = (uint64_t)c; c >>= 64; }
+    return r;
+}
+template <int NL> __device__ __forceinline__ wint<NL> wsub(const wint<NL> &a, const wint<NL> &b, bool &borrow_out) {
+    wint<NL> r; uint64_t borrow = 0;
+#pragma unroll
+    for (int i = 0; i < NL; i++) { u128_t d = (u128_t)a.l[i] - b.l[i] - borrow; r.l[i] = (uint64_t)d; borrow = (uint64_t)(d >> 64) & 1; }
+    borrow_out = borrow != 0;
+    return r;
+}
+// a, b < q < 2^(64 NL - 1): canonical sum / difference (the values add_mod / sub_mod of include/bigint.cuh:27-73 return on reduced operands)
+template <int NL> __device__ __forceinline__ wint<NL> waddmod(const wint<NL> &a, const wint<NL> &b, const wint<NL> &q) {
+    const wint<NL> s = wadd<NL>(a, b);
+    bool under; const wint<NL> d = wsub<NL>(s, q, under);
+    wint<NL> r;
+#pragma unroll
+    for (int i = 0; i < NL; i++) r.l[i] = under ? s.l[i] : d.l[i];
+    return r;
+}
+template <int NL> __device__ __forceinline__ wint<NL> wsubmod(const wint<NL> &a, const wint<NL> &b, const wint<NL> &q) {
+    bool under; const wint<NL> d = wsub<NL>(a, b, under);
+    const wint<NL> t = wadd<NL>(d, q);
+    wint<NL> r;
+#pragma unroll
+    for (int i = 0; i < NL; i++) r.l[i] = under ? t.l[i] : d.l[i];
+    return r;
+}
+
+// a * b * R^-1 mod q, canonical, for a, b < q (odd, < 2^(64 NL - 1)), R = 2^(64 NL); qinv32 = -q^-1 mod 2^32.
+// Same value as mul_mod_montgomery (include/bigint.cuh:76-140) would give with that radix; see mont_mul_fips in u256_dev.h.
+template <int NL>
+__device__ __forceinline__ wint<NL> wmont(const wint<NL> &a_, const wint<NL> &b_, const wint<NL> &q_, uint32_t qinv32) {
+    constexpr int NW = 2 * NL;
+    uint32_t a[NW], b[NW], q[NW], m[NW], t[NW];
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+        a[2 * i] = (uint32_t)a_.l[i]; a[2 * i + 1] = (uint32_t)(a_.l[i] >> 32);
+        b[2 * i] = (uint32_t)b_.l[i]; b[2 * i + 1] = (uint32_t)(b_.l[i] >> 32);
+        q[2 * i] = (uint32_t)q_.l[i]; q[2 * i + 1] = (uint32_t)(q_.l[i] >> 32);
+    }
+    uint64_t lo = 0; uint32_t hi = 0;
+#pragma unroll
+    for (int k = 0; k < 2 * NW - 1; k++) {
+        uint32_t xs[2 * NW], ys[2 * NW]; int cnt = 0;
+#pragma unroll
+        for (int i = 0; i < NW; i++) { const int j = k - i; if (j >= 0 && j < NW) { xs[cnt] = a[i]; ys[cnt] = b[j]; cnt++; } }
+#pragma unroll
+        for (int i = 0; i < NW; i++) { const int j = k - i; if (j >= 0 && j < NW && i < k) { xs[cnt] = m[i]; ys[cnt] = q[j]; cnt++; } }
+        int c = 0;
+#pragma unroll
+        for (int g = 0; g < (2 * NW + 2) / 3; g++) {
+            if (cnt - c >= 3) { mac3(lo, hi, xs[c], ys[c], xs[c + 1], ys[c + 1], xs[c + 2], ys[c + 2]); c += 3; }
+        }
+        if (cnt - c == 2) mac2(lo, hi, xs[c], ys[c], xs[c + 1], ys[c + 1]);
+        else if (cnt - c == 1) mac1(lo, hi, xs[c], ys[c]);
+        if (k < NW) {
+            m[k] = (uint32_t)lo * qinv32;
+            mac1(lo, hi, m[k], q[0]);              // clears the low word of the column
+        } else {
+            t[k - NW] = (uint32_t)lo;
+        }
+        lo = (lo >> 32) | ((uint64_t)hi << 32);
+        hi = 0;
+    }
+    t[NW - 1] = (uint32_t)lo;                       // the sum is below 2q < 2^(32 NW): nothing above this word
+    wint<NL> u;
+#pragma unroll
+    for (int i = 0; i < NL; i++) u.l[i] = (uint64_t)t[2 * i] | ((uint64_t)t[2 * i + 1] << 32);
+    bool under; const wint<NL> d = wsub<NL>(u, q_, under);
+    wint<NL> r;
+#pragma unroll
+    for (int i = 0; i < NL; i++) r.l[i] = under ? u.l[i] : d.l[i];
+    return r;
+}
+
+// ct_butterfly / gs_butterfly (include/ntt.cuh:147-167) on the radix-R product
+template <int NL> __device__ __forceinline__ void wct(wint<NL> &a, wint<NL> &b, const wint<NL> &w, const wint<NL> &q, uint32_t qi) {
+    const wint<NL> t = wmont<NL>(b, w, q, qi);
+    b = wsubmod<NL>(a, t, q);
+    a = waddmod<NL>(a, t, q);
+}
+template <int NL> __device__ __forceinline__ void wgs(wint<NL> &a, wint<NL> &b, const wint<NL> &w, const wint<NL> &q, uint32_t qi) {
+    const wint<NL> s = waddmod<NL>(a, b, q);
+    b = wmont<NL>(wsubmod<NL>(a, b, q), w, q, qi);
+    a = s;
+}
+
+// 32-byte container <-> registers.  NL = 2 reads the low 16 bytes (the upper words of a canonical residue are zero) and
+// writes them back as zeros.
+template <int NL> __device__ __forceinline__ wint<NL> wload_c(const u256 *p) {
+    const ulonglong2 *v = reinterpret_cast<const ulonglong2 *>(p);
+    wint<NL> r;
+    const ulonglong2 lo = v[0]; r.l[0] = lo.x; r.l[1] = lo.y;
+    if constexpr (NL == 4) { const ulonglong2 hi = v[1]; r.l[2] = hi.x; r.l[3] = hi.y; }
+    return r;
+}
+template <int NL> __device__ __forceinline__ void wstore_c(u256 *p, const wint<NL> &x) {
+    ulonglong2 *v = reinterpret_cast<ulonglong2 *>(p);
+    v[0] = make_ulonglong2(x.l[0], x.l[1]);
+    if constexpr (NL == 4) v[1] = make_ulonglong2(x.l[2], x.l[3]);
+    else v[1] = make_ulonglong2(0ull, 0ull);
+}
+template <int NL> __device__ __forceinline__ wint<NL> wload_t(const wint<NL> *p) {      // twiddle table entry (16-byte aligned)
+    const ulonglong2 *v = reinterpret_cast<const ulonglong2 *>(p);
+    wint<NL> r;
+#pragma unroll
+    for (int i = 0; i < NL / 2; i++) { const ulonglong2 t = v[i]; r.l[2 * i] = t.x; r.l[2 * i + 1] = t.y; }
+    return r;
+}
+
+// ---- global-memory pass over the top stages ---------------------------------------------------------------------------
+// FWD: stages s0 .. s0+R-1 (stage s works on index bit log_n-1-s).  INV: index bits b0 .. b0+R-1 ascending; `scale` != 0 multiplies
+// the outputs by n^-1 R (1) or n^-1 R^2 (2) -- only the pass that contains bit log_n-1 is launched with it.
+// src may differ from dst (the fused multiply transforms its operands into the workspace instead of copying them first).
+// grid = (ceil(n / 2^R / 256), polys).
+template <int NL, int R, bool FWD>
+__global__ void __launch_bounds__(256)
+wide_pass_kernel(u256 *dst, const u256 *src, const WLimb<NL> *__restrict__ limbs, uint32_t L, uint32_t log_n, uint32_t s0, uint32_t scale) {
+    const uint32_t n = 1u << log_n, u = blockIdx.x * 256 + threadIdx.x;
+    if (u >= (n >> R)) return;
+    const uint32_t p = blockIdx.y;
+    const WLimb<NL> &P = limbs[p % L];
+    const wint<NL> q = P.q; const uint32_t qi = P.qinv32;
+    const uint32_t b_lo = FWD ? log_n - s0 - R : s0;               // lowest index bit of the pass
+    const uint32_t i0 = ((u >> b_lo) << (b_lo + R)) | (u & ((1u << b_lo) - 1));
+    const u256 *in = src + (size_t)p * n; u256 *out = dst + (size_t)p * n;
+    wint<NL> x[1 << R];
+#pragma unroll
+    for (int k = 0; k < (1 << R); k++) x[k] = wload_c<NL>(in + i0 + ((uint32_t)k << b_lo));
+#pragma unroll
+    for (int j = 0; j < R; j++) {
+        const int pos = FWD ? R - 1 - j : j;                        // k-bit handled by this stage
+        const uint32_t b = b_lo + pos;
+#pragma unroll
+        for (int hh = 0; hh < (1 << (R - 1)); hh++) {
+            const int k = ((hh >> pos) << (pos + 1)) | (hh & ((1 << pos) - 1));
+            const uint32_t i = i0 + ((uint32_t)k << b_lo);
+            const wint<NL> w = wload_t<NL>((FWD ? P.tw : P.itw) + (n >> (b + 1)) + (i >> (b + 1)));
+            if (FWD) wct<NL>(x[k], x[k | (1 << pos)], w, q, qi);
+            else wgs<NL>(x[k], x[k | (1 << pos)], w, q, qi);
+        }
+    }
+    if (!FWD && scale) {
+        const wint<NL> c = scale == 2 ? P.ninv_r2 : P.ninv_m;
+#pragma unroll
+        for (int k = 0; k < (1 << R); k++) x[k] = wmont<NL>(x[k], c, q, qi);
+    }
+#pragma unroll
+    for (int k = 0; k < (1 << R); k++) wstore_c<NL>(out + i0 + ((uint32_t)k << b_lo), x[k]);
+}
+
+// ---- LDS tile: 2^11 coefficients, 256 threads x 8 ------------------------------------------------------------------------
+constexpr int WT_LOG = 11, WT_N = 1 << WT_LOG, WT_T = WT_N / 8;
+
+// XOR swizzle of the tile index (a permutation inside every aligned block of 32 slots, so the image needs no padding):
+// index bits 5, 6, 7 are folded into the bank bits as 5 -> {2}, 6 -> {0, 3}, 7 -> {1, 4}.  For each exchange pattern the five
+// index bits that vary over a 32-lane group then map to five independent bank bits:
+//   pattern B0 >= 5 : bits 0..4                       -> identity
+//   pattern B0 = 2  : bits 0, 1, 5, 6, 7              -> e0, e1, e2, e0+e3, e1+e4
+//   pattern B0 = 0  : bits 3, 4, 5, 6, 7              -> e3, e4, e2, e0+e3, e1+e4
+// (checked by SQ_LDS_BANK_CONFLICT = 0 in profiles/).  swz is linear over GF(2): swz(x ^ y) = swz(x) ^ swz(y).
+__device__ __host__ constexpr uint32_t swz(uint32_t i) {
+    return i ^ (((i >> 5) & 1u) << 2) ^ (((i >> 6) & 1u) * 9u) ^ (((i >> 7) & 1u) * 18u);
+}
+// pattern B0: register r <-> tile-index bits [B0, B0+3)
+template <int B0> __device__ __forceinline__ uint32_t wt_base(uint32_t tid) { return ((tid >> B0) << (B0 + 3)) | (tid & ((1u << B0) - 1)); }
+
+template <int NL, int B0>
+__device__ __forceinline__ void wt_put(uint32_t *lds, uint32_t tid, const wint<NL> (&x)[8]) {
+    const uint32_t pb = swz(wt_base<B0>(tid));
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        uint32_t *p = lds + (pb ^ swz((uint32_t)r << B0));
+#pragma unroll
+        for (int w = 0; w < 2 * NL; w++) p[w * WT_N] = (uint32_t)(x[r].l[w >> 1] >> (32 * (w & 1)));
+    }
+}
+template <int NL, int B0>
+__device__ __forceinline__ void wt_get(const uint32_t *lds, uint32_t tid, wint<NL> (&x)[8]) {
+    const uint32_t pb = swz(wt_base<B0>(tid));
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const uint32_t *p = lds + (pb ^ swz((uint32_t)r << B0));
+#pragma unroll
+        for (int i = 0; i < NL; i++) x[r].l[i] = (uint64_t)p[(2 * i) * WT_N] | ((uint64_t)p[(2 * i + 1) * WT_N] << 32);
+    }
+}
+
+// One register group: r-bits KHI .. KLO of pattern B0 (tile-index bits B0+KHI .. B0+KLO), forward order (descending).
+// gbase = index of the tile's first coefficient inside its polynomial.
+template <int NL, int B0, int K>
+__device__ __forceinline__ void wt_fwd_stage(wint<NL> (&x)[8], uint32_t ibase, uint32_t log_n, const WLimb<NL> &P, const wint<NL> &q) {
+    constexpr int b = B0 + K;
+    const wint<NL> *tw = P.tw + ((1u << (log_n - 1 - b)) + (ibase >> (b + 1)));
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        if (r & (1 << K)) continue;
+        const wint<NL> w = wload_t<NL>(tw + (r >> (K + 1)));
+        wct<NL>(x[r], x[r | (1 << K)], w, q, P.qinv32);
+    }
+}
+template <int NL, int B0, int K>
+__device__ __forceinline__ void wt_inv_stage(wint<NL> (&x)[8], uint32_t ibase, uint32_t log_n, const WLimb<NL> &P, const wint<NL> &q) {
+    constexpr int b = B0 + K;
+    const wint<NL> *tw = P.itw + ((1u << (log_n - 1 - b)) + (ibase >> (b + 1)));
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        if (r & (1 << K)) continue;
+        const wint<NL> w = wload_t<NL>(tw + (r >> (K + 1)));
+        wgs<NL>(x[r], x[r | (1 << K)], w, q, P.qinv32);
+    }
+}
+template <int NL, int B0, int KHI, int KLO>
+__device__ __forceinline__ void wt_fwd_group(wint<NL> (&x)[8], uint32_t tid, uint32_t gbase, uint32_t log_n, const WLimb<NL> &P, const wint<NL> &q) {
+    const uint32_t ibase = gbase + wt_base<B0>(tid);
+    wt_fwd_stage<NL, B0, KHI>(x, ibase, log_n, P, q);
+    if constexpr (KHI - 1 >= KLO) wt_fwd_stage<NL, B0, KHI - 1>(x, ibase, log_n, P, q);
+    if constexpr (KHI - 2 >= KLO) wt_fwd_stage<NL, B0, KHI - 2>(x, ibase, log_n, P, q);
+}
+template <int NL, int B0, int KLO, int KHI>
+__device__ __forceinline__ void wt_inv_group(wint<NL> (&x)[8], uint32_t tid, uint32_t gbase, uint32_t log_n, const WLimb<NL> &P, const wint<NL> &q) {
+    const uint32_t ibase = gbase + wt_base<B0>(tid);
+    wt_inv_stage<NL, B0, KLO>(x, ibase, log_n, P, q);
+    if constexpr (KLO + 1 <= KHI) wt_inv_stage<NL, B0, KLO + 1>(x, ibase, log_n, P, q);
+    if constexpr (KLO + 2 <= KHI) wt_inv_stage<NL, B0, KLO + 2>(x, ibase, log_n, P, q);
+}
+
+// the low 11 stages of a forward transform: coefficients in pattern 8 (coalesced order) -> values in pattern 0 (8 consecutive per thread)
+template <int NL>
+__device__ __forceinline__ void wt_forward(wint<NL> (&x)[8], uint32_t *lds, uint32_t tid, uint32_t gbase, uint32_t log_n, const WLimb<NL> &P, const wint<NL> &q) {
+    wt_fwd_group<NL, 8, 2, 0>(x, tid, gbase, log_n, P, q);          // tile bits 10, 9, 8
+    wt_put<NL, 8>(lds, tid, x);
+    __syncthreads();
+    wt_get<NL, 5>(lds, tid, x);
+    wt_fwd_group<NL, 5, 2, 0>(x, tid, gbase, log_n, P, q);          // 7, 6, 5
+    wt_put<NL, 5>(lds, tid, x);                                     // the slots this thread just read: no barrier needed before
+    __syncthreads();
+    wt_get<NL, 2>(lds, tid, x);
+    wt_fwd_group<NL, 2, 2, 0>(x, tid, gbase, log_n, P, q);          // 4, 3, 2
+    wt_put<NL, 2>(lds, tid, x);
+    __syncthreads();
+    wt_get<NL, 0>(lds, tid, x);
+    wt_fwd_group<NL, 0, 1, 0>(x, tid, gbase, log_n, P, q);          // 1, 0
+}
+// the low 11 stages of an inverse transform: values in pattern 0 -> coefficients in pattern 8
+template <int NL>
+__device__ __forceinline__ void wt_inverse(wint<NL> (&x)[8], uint32_t *lds, uint32_t tid, uint32_t gbase, uint32_t log_n, const WLimb<NL> &P, const wint<NL> &q) {
+    wt_inv_group<NL, 0, 0, 1>(x, tid, gbase, log_n, P, q);          // tile bits 0, 1
+    wt_put<NL, 0>(lds, tid, x);
+    __syncthreads();
+    wt_get<NL, 2>(lds, tid, x);
+    wt_inv_group<NL, 2, 0, 2>(x, tid, gbase, log_n, P, q);          // 2, 3, 4
+    wt_put<NL, 2>(lds, tid, x);
+    __syncthreads();
+    wt_get<NL, 5>(lds, tid, x);
+    wt_inv_group<NL, 5, 0, 2>(x, tid, gbase, log_n, P, q);          // 5, 6, 7
+    wt_put<NL, 5>(lds, tid, x);
+    __syncthreads();
+    wt_get<NL, 8>(lds, tid, x);
+    wt_inv_group<NL, 8, 0, 2>(x, tid, gbase, log_n, P, q);          // 8, 9, 10
+}
+
+enum { TILE_FWD = 0, TILE_INV = 1, TILE_MUL = 2 };
+
+// grid.x = polys * (n / 2^11): workgroup g handles tile g % tiles of polynomial g / tiles (limb = polynomial % L).
+//   TILE_FWD : dst tile = low 11 forward stages of src tile (the top stages were done by wide_pass_kernel<.., true>)
+//   TILE_INV : dst tile = low 11 inverse stages of src tile; scale as in wide_pass_kernel (applied when n = 2^11)
+//   TILE_MUL : dst tile = inverse stages of (forward(src tile) .* forward(src2 tile)); the result carries R^-1 until the scaling
+//              by n^-1 R^2 (here when n = 2^11, else in the inverse top pass)
+// dst may alias src / src2 tile for tile: every workgroup loads its tiles completely before its first store.
+template <int NL, int MODE>
+__global__ void __launch_bounds__(WT_T, 2)
+wide_tile_kernel(u256 *dst, const u256 *src, const u256 *src2, const WLimb<NL> *__restrict__ limbs, uint32_t L, uint32_t log_n, uint32_t scale) {
+    __shared__ uint32_t lds[2 * NL * WT_N];
+    const uint32_t tid = threadIdx.x, tiles = 1u << (log_n - WT_LOG);
+    const uint32_t p = blockIdx.x >> (log_n - WT_LOG), tile = blockIdx.x & (tiles - 1);
+    const WLimb<NL> &P = limbs[p % L];
+    const wint<NL> q = P.q;
+    const uint32_t gbase = tile << WT_LOG;
+    const size_t off = ((size_t)p << log_n) + gbase;
+    wint<NL> x[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) x[r] = wload_c<NL>(src + off + tid + r * WT_T);
+    if constexpr (MODE == TILE_FWD) {
+        wt_forward<NL>(x, lds, tid, gbase, log_n, P, q);
+        wt_put<NL, 0>(lds, tid, x);
+        __syncthreads();
+        wt_get<NL, 8>(lds, tid, x);                                 // back to the coalesced order for the store
+    } else if constexpr (MODE == TILE_INV) {
+        wt_put<NL, 8>(lds, tid, x);
+        __syncthreads();
+        wt_get<NL, 0>(lds, tid, x);
+        wt_inverse<NL>(x, lds, tid, gbase, log_n, P, q);
+    } else {
+        wint<NL> y[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) y[r] = wload_c<NL>(src2 + off + tid + r * WT_T);   // issued early: hides under a's butterflies
+        wt_forward<NL>(x, lds, tid, gbase, log_n, P, q);
+        __syncthreads();                                            // a's last exchange reads are over before b's first put
+        wt_forward<NL>(y, lds, tid, gbase, log_n, P, q);
+#pragma unroll
+        for (int r = 0; r < 8; r++) x[r] = wmont<NL>(x[r], y[r], q, P.qinv32);
+        wt_inverse<NL>(x, lds, tid, gbase, log_n, P, q);            // starts in the pattern both transforms ended in: no exchange
+    }
+    if (MODE != TILE_FWD && scale) {
+        const wint<NL> c = scale == 2 ? P.ninv_r2 : P.ninv_m;
+#pragma unroll
+        for (int r = 0; r < 8; r++) x[r] = wmont<NL>(x[r], c, q, P.qinv32);
+    }
+#pragma unroll
+    for (int r = 0; r < 8; r++) wstore_c<NL>(dst + off + tid + r * WT_T, x[r]);
+}
+
+// r = mont(a, b) per coefficient (NTT domain; carries R^-1 until the n^-1 R^2 scaling of the inverse transform that follows)
+template <int NL>
+__global__ void __launch_bounds__(256)
+wide_pointwise_kernel(u256 *r, const u256 *a, const u256 *b, const WLimb<NL> *__restrict__ limbs, uint32_t L, uint32_t log_n, size_t count) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < count; g += stride) {
+        const WLimb<NL> &P = limbs[(uint32_t)((g >> log_n) % L)];
+        wstore_c<NL>(r + g, wmont<NL>(wload_c<NL>(a + g), wload_c<NL>(b + g), P.q, P.qinv32));
+    }
+}
+
+// x *= n^-1 R (scale 1) or n^-1 R^2 (scale 2) per coefficient: the whole "inverse transform" of a degree-1 engine (an RNS base without
+// a ring, fhe_rns_base_create), whose butterfly network is empty.
+template <int NL>
+__global__ void __launch_bounds__(256)
+wide_scale_kernel(u256 *r, const u256 *a, const WLimb<NL> *__restrict__ limbs, uint32_t L, uint32_t log_n, uint32_t scale, size_t count) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < count; g += stride) {
+        const WLimb<NL> &P = limbs[(uint32_t)((g >> log_n) % L)];
+        wstore_c<NL>(r + g, wmont<NL>(wload_c<NL>(a + g), scale == 2 ? P.ninv_r2 : P.ninv_m, P.q, P.qinv32));
+    }
+}
+
+// Tensor product in the NTT domain (FHEContext::multiply, src/fhe.cu:199-218) on four transformed operands, one pass:
+// c0 = a0 b0, c1 = a0 b1 + a1 b0, c2 = a1 b1, every product a single Montgomery product (results carry R^-1, removed by the
+// n^-1 R^2 scaling of the inverse transforms that follow).  One coefficient per lane.
+template <int NL>
+__global__ void __launch_bounds__(256)
+wide_ct_pointwise_kernel(u256 *c0, u256 *c1, u256 *c2, const u256 *a0, const u256 *a1, const u256 *b0, const u256 *b1,
+                         const WLimb<NL> *__restrict__ limbs, uint32_t L, uint32_t log_n, size_t count) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < count; g += stride) {
+        const WLimb<NL> &P = limbs[(uint32_t)((g >> log_n) % L)];
+        const wint<NL> q = P.q; const uint32_t qi = P.qinv32;
+        const wint<NL> u0 = wload_c<NL>(a0 + g), u1 = wload_c<NL>(a1 + g), v0 = wload_c<NL>(b0 + g), v1 = wload_c<NL>(b1 + g);
+        wstore_c<NL>(c0 + g, wmont<NL>(u0, v0, q, qi));
+        wstore_c<NL>(c1 + g, waddmod<NL>(wmont<NL>(u0, v1, q, qi), wmont<NL>(u1, v0, q, qi), q));
+        wstore_c<NL>(c2 + g, wmont<NL>(u1, v1, q, qi));
+    }
+}
+
+}  // namespace fhe_dev

@@ -19,32 +19,34 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 t0 = time.time(); cases = 0; launches = 0
 while time.time() - t0 < budget:
     log_n = int(rng.integers(11, 16)); n = 1 << log_n
-    bits = int(rng.choice([30, 30, 30, 40, 60])) if log_n <= 14 else 30
+    bits = int(rng.choice([30, 30, 30, 40, 60, 64])) if log_n <= 14 else 30
     L = int(rng.integers(1, 7 if bits == 30 else 4))
     w = int(rng.choice([8, 16, 20, 30])) if bits == 30 else int(rng.choice([16, 20, 32]))
     batch = int(rng.integers(1, 41)) if log_n <= 13 else int(rng.integers(1, 9))
     moduli = pkg.find_ntt_primes(bits, n, L)
-    eng = pkg.RnsNttEngine(n, moduli)
-    K = eng.relin_num_digits(w)
+    # the environment switches are read once, at engine creation: one engine per kernel family
+    def make(**env):
+        for k, v in env.items():
+            os.environ[k] = v
+        try:
+            return pkg.RnsNttEngine(n, moduli)
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+    engs = {"fused": make(), "general": make(FHE_HIP_NO_FUSED_KEYSWITCH="1", FHE_HIP_NO_FUSED_BLIND_ROTATE="1"),
+            "fused-single": make(FHE_HIP_NO_PAIRED_TRANSFORMS="1")}
+    K = engs["fused"].relin_num_digits(w)
     seed = int(rng.integers(1 << 30))
     keys = [[pkg.DeviceBuffer.from_numpy(rns_poly(seed + 31 * i + 997 * h, moduli, n, 1)) for i in range(L * K)] for h in range(4)]
-    os.environ.pop("FHE_HIP_NO_FUSED_KEYSWITCH", None)
-    fused = [eng.import_relin_keys(w, keys[0], keys[1]), eng.import_relin_keys(w, keys[2], keys[3])]
-    os.environ["FHE_HIP_NO_FUSED_KEYSWITCH"] = "1"
-    general = [eng.import_relin_keys(w, keys[0], keys[1]), eng.import_relin_keys(w, keys[2], keys[3])]
-    os.environ.pop("FHE_HIP_NO_FUSED_KEYSWITCH", None)
+    keysets = {tag: [e.import_relin_keys(w, keys[0], keys[1]), e.import_relin_keys(w, keys[2], keys[3])] for tag, e in engs.items()}
     c = [rns_poly(seed + 5000 + i, moduli, n, batch) for i in range(3)]
     shape = c[0].shape
     # relinearisation, repeated: every repetition must give the same bits
     want = None
     for rep in range(4):
-        for keyset, tag in ((general, "general"), (fused, "fused"), (fused, "fused-single")):
-            if tag == "fused-single":
-                os.environ["FHE_HIP_NO_PAIRED_TRANSFORMS"] = "1"       # the one-transform-at-a-time kernels, too
-            else:
-                os.environ.pop("FHE_HIP_NO_PAIRED_TRANSFORMS", None)
+        for tag in ("general", "fused", "fused-single"):
             d = [pkg.DeviceBuffer.from_numpy(x) for x in c]
-            eng.relinearize(keyset[0], d[0], d[1], d[2], batch); launches += 1
+            engs[tag].relinearize(keysets[tag][0], d[0], d[1], d[2], batch); launches += 1
             got = (d[0].download(shape), d[1].download(shape))
             if want is None:
                 want = got
@@ -56,24 +58,16 @@ while time.time() - t0 < budget:
     dSh = pkg.DeviceBuffer.from_numpy(shifts)
     want = None
     for rep in range(3):
-        for keyset, env, tag in ((general, "1", "general"), (fused, None, "fused"), (fused, None, "fused-single")):
-            if tag == "fused-single":
-                os.environ["FHE_HIP_NO_PAIRED_TRANSFORMS"] = "1"
-            else:
-                os.environ.pop("FHE_HIP_NO_PAIRED_TRANSFORMS", None)
-            if env:
-                os.environ["FHE_HIP_NO_FUSED_BLIND_ROTATE"] = env
-            else:
-                os.environ.pop("FHE_HIP_NO_FUSED_BLIND_ROTATE", None)
+        for tag in ("general", "fused", "fused-single"):
             a0, a1 = pkg.DeviceBuffer.from_numpy(c[0]), pkg.DeviceBuffer.from_numpy(c[1])
             t0b, t1b = pkg.DeviceBuffer(c[0].nbytes), pkg.DeviceBuffer(c[0].nbytes)
-            eng.blind_rotate([keyset[0]] * steps, [keyset[1]] * steps, a0, a1, dSh, t0b, t1b, batch); launches += steps
+            engs[tag].blind_rotate([keysets[tag][0]] * steps, [keysets[tag][1]] * steps, a0, a1, dSh, t0b, t1b, batch); launches += steps
             got = (a0.download(shape), a1.download(shape))
             if want is None:
                 want = got
             elif not (np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])):
                 print(f"MISMATCH blind_rotate {tag} n={n} bits={bits} L={L} w={w} batch={batch} steps={steps} seed={seed} rep={rep}"); sys.exit(1)
-    os.environ.pop("FHE_HIP_NO_FUSED_BLIND_ROTATE", None); os.environ.pop("FHE_HIP_NO_PAIRED_TRANSFORMS", None)
+    del keysets, engs
     cases += 1
     if cases % 10 == 0:
         print(f"{cases} shapes, {launches} launches, {time.time() - t0:.0f} s", flush=True)

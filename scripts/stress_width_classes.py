@@ -33,15 +33,20 @@ while time.time() - t0 < budget:
     fast = pkg.RnsNttEngine(n, moduli)
     os.environ["FHE_HIP_FORCE_WIDTH"] = "256"
     wide = pkg.RnsNttEngine(n, moduli)
+    os.environ["FHE_HIP_FORCE_WIDTH"] = "128"          # the same class on two 64-bit limbs (R = 2^128)
+    wide2 = pkg.RnsNttEngine(n, moduli)
+    os.environ["FHE_HIP_NO_WIDE_TILES"] = "1"          # and with every stage as a global-memory pass (no LDS tiles)
+    wide2p = pkg.RnsNttEngine(n, moduli)
+    os.environ.pop("FHE_HIP_NO_WIDE_TILES", None)
     os.environ.pop("FHE_HIP_FORCE_WIDTH", None)
-    assert fast.width_class != pkg.WIDTH_256 and wide.width_class == pkg.WIDTH_256
+    assert fast.width_class != pkg.WIDTH_256 and wide.width_class == pkg.WIDTH_256 and wide2.width_class == pkg.WIDTH_256
     seed = int(rng.integers(1 << 30))
     x = [rns_poly(seed + i, moduli, n, batch) for i in range(4)]
     shape = x[0].shape
     info = dict(n=n, bits=bits, L=L, batch=batch, seed=seed)
     ref = {}
     for rep in range(3):
-        for eng, tag in ((wide, "wide"), (fast, "fast"), (fast, "fast")):
+        for eng, tag in ((wide, "wide"), (fast, "fast"), (wide2, "wide-2-limb"), (wide2p, "wide-2-limb-passes"), (fast, "fast"))[:5 if rep == 0 else 2]:
             d = [pkg.DeviceBuffer.from_numpy(v) for v in x]
             o = [pkg.DeviceBuffer(x[0].nbytes) for _ in range(3)]
             eng.multiply(o[0], d[0], d[1], batch); launches += 1

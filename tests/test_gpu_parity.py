@@ -86,6 +86,16 @@ CASES = [
     (4096, ("mix", (64, 1), (50, 1), (63, 1)), 2, 5),   # one wide prime pulls the whole basis onto the full-range path
     (32768, ("bits", 64, 1), 1, 4),             # beyond the LDS range of 8-byte residues: general path
     (65536, ("bits", 30, 1), 1, 4),             # larger than LDS: general path
+    # full-width class, LDS-staged tiles of 2^11 coefficients (ntt_wide.hip.h): two-limb (q < 2^127) and four-limb residues,
+    # one tile per polynomial, 1-3 top stages in one global pass, 4-5 in two
+    (2048, ("bits", 120, 2), 2, 4),
+    (2048, ("bits", 255, 1), 3, 4),
+    (8192, ("bits", 127, 2), 2, 4),
+    (8192, ("bits", 250, 2), 2, 4),             # the shape of the round-1 full-width bench line
+    (16384, ("bits", 200, 1), 1, 4),
+    (32768, ("bits", 128, 1), 1, 4),
+    (65536, ("bits", 100, 1), 1, 4),
+    (4096, ("mix", (250, 1), (30, 1), (100, 1)), 2, 4),
 ]
 
 
@@ -141,7 +151,7 @@ def test_forward_inverse_multiply_match_oracle(eng, oracle, n, spec, batch, widt
 
 
 @pytest.mark.parametrize("n,spec,batch", [(2048, [40961], 2), (8192, ("bits", 30, 4), 2), (4096, ("bits", 60, 2), 1),
-                                          (16384, ("bits", 40, 6), 1), (256, ("bits", 250, 2), 1), (8192, ("bits", 64, 2), 1), (16384, ("bits", 64, 1), 1)])
+                                          (16384, ("bits", 40, 6), 1), (256, ("bits", 250, 2), 1), (8192, ("bits", 64, 2), 1), (16384, ("bits", 64, 1), 1), (8192, ("bits", 250, 1), 2), (4096, ("bits", 100, 2), 1)])
 def test_ct_multiply_matches_oracle(eng, oracle, n, spec, batch):
     """FHEContext::multiply tensor product (src/fhe.cu:199-218)."""
     moduli = _moduli(spec, n)
@@ -176,7 +186,7 @@ def test_single_modulus_engine_reference_scenarios(eng, oracle):
     assert np.array_equal(dR.download(), p.schoolbook(a, b))
 
 
-@pytest.mark.parametrize("force,width", [("64", 2), ("65", 5), ("256", 4)])
+@pytest.mark.parametrize("force,width", [("64", 2), ("65", 5), ("128", 4), ("256", 4)])
 def test_forced_wider_paths_agree(eng, oracle, monkeypatch, force, width):
     """The same 40-bit basis through the 64-bit integer path and the full-width path (FHE_HIP_FORCE_WIDTH)."""
     n = 4096; moduli = nm.ntt_primes(40, n, 2); batch = 2
@@ -520,7 +530,7 @@ def test_from_rns_rejects_oversized_basis(eng):
     e.to_rns(buf, out, 1)          # to_rns has no such limit
 
 
-@pytest.mark.parametrize("n,bits,L", [(8192, 30, 2), (4096, 40, 2), (2048, 60, 1), (256, 250, 1), (2048, 64, 2)])
+@pytest.mark.parametrize("n,bits,L", [(8192, 30, 2), (4096, 40, 2), (2048, 60, 1), (256, 250, 1), (2048, 64, 2), (2048, 250, 1), (8192, 100, 1)])
 def test_in_place_multiply_and_squaring(eng, oracle, n, bits, L):
     """Like the reference (which copies its operands, src/ntt.cu:50-58) the result may alias an operand."""
     moduli = nm.ntt_primes(bits, n, L)
