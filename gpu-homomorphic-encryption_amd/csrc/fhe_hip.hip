@@ -439,7 +439,7 @@ static int build_wlimbs(fhe_rns_ntt *h, const std::vector<fhe_host::NttConstants
         fhe_host::Mod M(c.q);
         U256 Rn = M.r1;                                   // 2^256 mod q
         if (NL == 2) { U256 t; t.w[2] = 1; Rn = M.reduce(t); }   // 2^128 mod q
-        auto put = [](W &dst, const U256 &v) { for (int i = 0; i < NL; i++) dst.l[i] = v.w[i]; };
+        auto put = [](W &dst, const U256 &v) { for (int i = 0; i < NL; i++) { dst.w[2 * i] = (uint32_t)v.w[i]; dst.w[2 * i + 1] = (uint32_t)(v.w[i] >> 32); } };
         std::vector<W> tw(h->n), itw(h->n);
         for (uint32_t k = 0; k < h->n; k++) { put(tw[k], M.mul(c.tw[k], Rn)); put(itw[k], M.mul(c.itw[k], Rn)); }
         fhe_dev::WLimb<NL> &P = limbs[l];

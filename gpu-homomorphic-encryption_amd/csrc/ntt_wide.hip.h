@@ -26,7 +26,11 @@
 
 namespace fhe_dev {
 
-template <int NL> struct wint { uint64_t l[NL]; };
+typedef uint32_t v4u32w __attribute__((ext_vector_type(4)));
+
+template <int NL> struct __attribute__((aligned(16))) wint { uint32_t w[2 * NL]; };   // 2 NL little-endian 32-bit words
+
+#include "wide_asm.inc"
 
 // Per-limb constants of the wide NTT kernels (device memory, one entry per RNS prime).
 template <int NL>
@@ -40,116 +44,83 @@ struct WLimb {
     const wint<NL> *itw;  // [n] psi^-bitrev(k) * R mod q
 };
 
-template <int NL> __device__ __forceinline__ wint<NL> wadd(const wint<NL> &a, const wint<NL> &b) {
-    wint<NL> r; u128_t c = 0;
-#pragma unroll
-    for (int i = 0; i < NL; i++) { c += (u128_t)a.l[i] + b.l[i]; r.l[i] = (uint64_t)c; c >>= 64; }
-    return r;
-}
-template <int NL> __device__ __forceinline__ wint<NL> wsub(const wint<NL> &a, const wint<NL> &b, bool &borrow_out) {
-    wint<NL> r; uint64_t borrow = 0;
-#pragma unroll
-    for (int i = 0; i < NL; i++) { u128_t d = (u128_t)a.l[i] - b.l[i] - borrow; r.l[i] = (uint64_t)d; borrow = (uint64_t)(d >> 64) & 1; }
-    borrow_out = borrow != 0;
-    return r;
-}
-// a, b < q < 2^(64 NL - 1): canonical sum / difference (the values add_mod / sub_mod of include/bigint.cuh:27-73 return on reduced operands)
-template <int NL> __device__ __forceinline__ wint<NL> waddmod(const wint<NL> &a, const wint<NL> &b, const wint<NL> &q) {
-    const wint<NL> s = wadd<NL>(a, b);
-    bool under; const wint<NL> d = wsub<NL>(s, q, under);
-    wint<NL> r;
-#pragma unroll
-    for (int i = 0; i < NL; i++) r.l[i] = under ? s.l[i] : d.l[i];
-    return r;
-}
-template <int NL> __device__ __forceinline__ wint<NL> wsubmod(const wint<NL> &a, const wint<NL> &b, const wint<NL> &q) {
-    bool under; const wint<NL> d = wsub<NL>(a, b, under);
-    const wint<NL> t = wadd<NL>(d, q);
-    wint<NL> r;
-#pragma unroll
-    for (int i = 0; i < NL; i++) r.l[i] = under ? t.l[i] : d.l[i];
-    return r;
-}
-
-// a * b * R^-1 mod q, canonical, for a, b < q (odd, < 2^(64 NL - 1)), R = 2^(64 NL); qinv32 = -q^-1 mod 2^32.
-// Same value as mul_mod_montgomery (include/bigint.cuh:76-140) would give with that radix; see mont_mul_fips in u256_dev.h.
-template <int NL>
-__device__ __forceinline__ wint<NL> wmont(const wint<NL> &a_, const wint<NL> &b_, const wint<NL> &q_, uint32_t qinv32) {
+// a * b * R^-1 mod q, canonical, for a, b < q (odd, < 2^(64 NL - 1)), R = 2^(64 NL); qinv32 = -q^-1 mod 2^32.  The value
+// mul_mod_montgomery (include/bigint.cuh:76-140) returns with that radix.  Finely integrated product scanning over 32-bit
+// words: column k sums a_i b_(k-i) and m_i q_(k-i) in one asm block (wide_asm.inc: macn), m_k = column * qinv clears its low
+// word, and the words of the result are compared against q as they become final (macn_e), so the closing conditional
+// subtraction is two more steps and a select (wsel).
+template <int NL, int K>
+__device__ __forceinline__ void wmont_column(uint64_t &lo, uint32_t &hi, const uint32_t (&a)[2 * NL], const uint32_t (&b)[2 * NL], const uint32_t (&q)[2 * NL],
+                                             uint32_t (&m)[2 * NL], uint32_t (&t)[2 * NL], uint32_t (&tq)[2 * NL], uint64_t &bor, uint32_t qinv32) {
     constexpr int NW = 2 * NL;
-    uint32_t a[NW], b[NW], q[NW], m[NW], t[NW];
+    constexpr int CNT_AB = (K < NW ? K + 1 : 2 * NW - 1 - K), CNT_MQ = (K < NW ? K : 2 * NW - 1 - K), CNT = CNT_AB + CNT_MQ;
+    uint32_t xs[16], ys[16];
+    int cnt = 0;
 #pragma unroll
-    for (int i = 0; i < NL; i++) {
-        a[2 * i] = (uint32_t)a_.l[i]; a[2 * i + 1] = (uint32_t)(a_.l[i] >> 32);
-        b[2 * i] = (uint32_t)b_.l[i]; b[2 * i + 1] = (uint32_t)(b_.l[i] >> 32);
-        q[2 * i] = (uint32_t)q_.l[i]; q[2 * i + 1] = (uint32_t)(q_.l[i] >> 32);
+    for (int i = 0; i < NW; i++) { const int j = K - i; if (j >= 0 && j < NW) { xs[cnt] = a[i]; ys[cnt] = b[j]; cnt++; } }
+#pragma unroll
+    for (int i = 0; i < NW; i++) { const int j = K - i; if (j >= 0 && j < NW && i < K) { xs[cnt] = m[i]; ys[cnt] = q[j]; cnt++; } }
+    if constexpr (K == NW + 1) macn_e0<CNT>(lo, hi, bor, tq[0], t[0], q[0], xs, ys);
+    else if constexpr (K > NW + 1) macn_e<CNT>(lo, hi, bor, tq[K - NW - 1], t[K - NW - 1], q[K - NW - 1], xs, ys);
+    else macn<CNT>(lo, hi, xs, ys);
+    if constexpr (K < NW) {
+        m[K] = (uint32_t)lo * qinv32;
+        macn_1(lo, hi, m[K], q[0]);                 // clears the low word of the column
+    } else {
+        t[K - NW] = (uint32_t)lo;
     }
-    uint64_t lo = 0; uint32_t hi = 0;
-#pragma unroll
-    for (int k = 0; k < 2 * NW - 1; k++) {
-        uint32_t xs[2 * NW], ys[2 * NW]; int cnt = 0;
-#pragma unroll
-        for (int i = 0; i < NW; i++) { const int j = k - i; if (j >= 0 && j < NW) { xs[cnt] = a[i]; ys[cnt] = b[j]; cnt++; } }
-#pragma unroll
-        for (int i = 0; i < NW; i++) { const int j = k - i; if (j >= 0 && j < NW && i < k) { xs[cnt] = m[i]; ys[cnt] = q[j]; cnt++; } }
-        int c = 0;
-#pragma unroll
-        for (int g = 0; g < (2 * NW + 2) / 3; g++) {
-            if (cnt - c >= 3) { mac3(lo, hi, xs[c], ys[c], xs[c + 1], ys[c + 1], xs[c + 2], ys[c + 2]); c += 3; }
-        }
-        if (cnt - c == 2) mac2(lo, hi, xs[c], ys[c], xs[c + 1], ys[c + 1]);
-        else if (cnt - c == 1) mac1(lo, hi, xs[c], ys[c]);
-        if (k < NW) {
-            m[k] = (uint32_t)lo * qinv32;
-            mac1(lo, hi, m[k], q[0]);              // clears the low word of the column
-        } else {
-            t[k - NW] = (uint32_t)lo;
-        }
-        lo = (lo >> 32) | ((uint64_t)hi << 32);
-        hi = 0;
-    }
-    t[NW - 1] = (uint32_t)lo;                       // the sum is below 2q < 2^(32 NW): nothing above this word
-    wint<NL> u;
-#pragma unroll
-    for (int i = 0; i < NL; i++) u.l[i] = (uint64_t)t[2 * i] | ((uint64_t)t[2 * i + 1] << 32);
-    bool under; const wint<NL> d = wsub<NL>(u, q_, under);
-    wint<NL> r;
-#pragma unroll
-    for (int i = 0; i < NL; i++) r.l[i] = under ? u.l[i] : d.l[i];
-    return r;
+    lo = (lo >> 32) | ((uint64_t)hi << 32);
+    hi = 0;
+    if constexpr (K + 1 < 2 * NW - 1) wmont_column<NL, K + 1>(lo, hi, a, b, q, m, t, tq, bor, qinv32);
+}
+template <int NL>
+__device__ __forceinline__ wint<NL> wmont(const wint<NL> &a, const wint<NL> &b, const wint<NL> &q, uint32_t qinv32) {
+    constexpr int NW = 2 * NL;
+    uint32_t m[NW], tq[NW];
+    wint<NL> t;
+    uint64_t lo = 0, bor = 0; uint32_t hi = 0;
+    wmont_column<NL, 0>(lo, hi, a.w, b.w, q.w, m, t.w, tq, bor, qinv32);
+    t.w[NW - 1] = (uint32_t)lo;                      // the sum is below 2q < 2^(32 NW): nothing above this word
+    if constexpr (NL == 4) wsel_8(t.w, tq, q.w, bor); else wsel_4(t.w, tq, q.w, bor);
+    return t;
+}
+template <int NL> __device__ __forceinline__ void waddsub(wint<NL> &a, wint<NL> &t, const wint<NL> &q) {
+    if constexpr (NL == 4) waddsub_8(a.w, t.w, q.w); else waddsub_4(a.w, t.w, q.w);
 }
 
-// ct_butterfly / gs_butterfly (include/ntt.cuh:147-167) on the radix-R product
+// ct_butterfly / gs_butterfly (include/ntt.cuh:147-167) on the radix-R product: (a, b) <- (a + b w, a - b w) / (a + b, (a - b) w)
 template <int NL> __device__ __forceinline__ void wct(wint<NL> &a, wint<NL> &b, const wint<NL> &w, const wint<NL> &q, uint32_t qi) {
-    const wint<NL> t = wmont<NL>(b, w, q, qi);
-    b = wsubmod<NL>(a, t, q);
-    a = waddmod<NL>(a, t, q);
+    b = wmont<NL>(b, w, q, qi);
+    waddsub<NL>(a, b, q);
 }
 template <int NL> __device__ __forceinline__ void wgs(wint<NL> &a, wint<NL> &b, const wint<NL> &w, const wint<NL> &q, uint32_t qi) {
-    const wint<NL> s = waddmod<NL>(a, b, q);
-    b = wmont<NL>(wsubmod<NL>(a, b, q), w, q, qi);
-    a = s;
+    waddsub<NL>(a, b, q);
+    b = wmont<NL>(b, w, q, qi);
 }
+// a + b mod q alone (tensor product): the butterfly tail on copies
+template <int NL> __device__ __forceinline__ wint<NL> waddmod(wint<NL> a, wint<NL> b, const wint<NL> &q) { waddsub<NL>(a, b, q); return a; }
 
 // 32-byte container <-> registers.  NL = 2 reads the low 16 bytes (the upper words of a canonical residue are zero) and
 // writes them back as zeros.
 template <int NL> __device__ __forceinline__ wint<NL> wload_c(const u256 *p) {
-    const ulonglong2 *v = reinterpret_cast<const ulonglong2 *>(p);
+    const v4u32w *v = reinterpret_cast<const v4u32w *>(p);
     wint<NL> r;
-    const ulonglong2 lo = v[0]; r.l[0] = lo.x; r.l[1] = lo.y;
-    if constexpr (NL == 4) { const ulonglong2 hi = v[1]; r.l[2] = hi.x; r.l[3] = hi.y; }
+    const v4u32w lo = v[0]; r.w[0] = lo.x; r.w[1] = lo.y; r.w[2] = lo.z; r.w[3] = lo.w;
+    if constexpr (NL == 4) { const v4u32w hi = v[1]; r.w[4] = hi.x; r.w[5] = hi.y; r.w[6] = hi.z; r.w[7] = hi.w; }
     return r;
 }
 template <int NL> __device__ __forceinline__ void wstore_c(u256 *p, const wint<NL> &x) {
-    ulonglong2 *v = reinterpret_cast<ulonglong2 *>(p);
-    v[0] = make_ulonglong2(x.l[0], x.l[1]);
-    if constexpr (NL == 4) v[1] = make_ulonglong2(x.l[2], x.l[3]);
-    else v[1] = make_ulonglong2(0ull, 0ull);
+    v4u32w *v = reinterpret_cast<v4u32w *>(p);
+    v4u32w lo = {x.w[0], x.w[1], x.w[2], x.w[3]};
+    v[0] = lo;
+    if constexpr (NL == 4) { v4u32w hi = {x.w[4], x.w[5], x.w[6], x.w[7]}; v[1] = hi; }
+    else { v4u32w z = {0u, 0u, 0u, 0u}; v[1] = z; }
 }
-template <int NL> __device__ __forceinline__ wint<NL> wload_t(const wint<NL> *p) {      // twiddle table entry (16-byte aligned)
-    const ulonglong2 *v = reinterpret_cast<const ulonglong2 *>(p);
+template <int NL> __device__ __forceinline__ wint<NL> wload_t(const wint<NL> *p) {      // table entry (16-byte aligned)
+    const v4u32w *v = reinterpret_cast<const v4u32w *>(p);
     wint<NL> r;
 #pragma unroll
-    for (int i = 0; i < NL / 2; i++) { const ulonglong2 t = v[i]; r.l[2 * i] = t.x; r.l[2 * i + 1] = t.y; }
+    for (int i = 0; i < NL / 2; i++) { const v4u32w t = v[i]; r.w[4 * i] = t.x; r.w[4 * i + 1] = t.y; r.w[4 * i + 2] = t.z; r.w[4 * i + 3] = t.w; }
     return r;
 }
 
@@ -217,7 +188,7 @@ __device__ __forceinline__ void wt_put(uint32_t *lds, uint32_t tid, const wint<N
     for (int r = 0; r < 8; r++) {
         uint32_t *p = lds + (pb ^ swz((uint32_t)r << B0));
 #pragma unroll
-        for (int w = 0; w < 2 * NL; w++) p[w * WT_N] = (uint32_t)(x[r].l[w >> 1] >> (32 * (w & 1)));
+        for (int w = 0; w < 2 * NL; w++) p[w * WT_N] = x[r].w[w];
     }
 }
 template <int NL, int B0>
@@ -227,7 +198,7 @@ __device__ __forceinline__ void wt_get(const uint32_t *lds, uint32_t tid, wint<N
     for (int r = 0; r < 8; r++) {
         const uint32_t *p = lds + (pb ^ swz((uint32_t)r << B0));
 #pragma unroll
-        for (int i = 0; i < NL; i++) x[r].l[i] = (uint64_t)p[(2 * i) * WT_N] | ((uint64_t)p[(2 * i + 1) * WT_N] << 32);
+        for (int w = 0; w < 2 * NL; w++) x[r].w[w] = p[w * WT_N];
     }
 }
 
