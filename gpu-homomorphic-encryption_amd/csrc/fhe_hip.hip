@@ -246,6 +246,7 @@ struct fhe_rns_ntt {
     hipStream_t own_stream = nullptr, stream = nullptr;
     void *d_limbs = nullptr;            // owned by d_tables
     void *d_wlimbs = nullptr;           // FHE_WIDTH_256: WLimb<wide_nl>[L] for the NTT kernels of ntt_wide.hip.h (owned by d_tables)
+    uint32_t sub_top = 0;               // word-sized classes beyond the LDS range: log2 n = 13 + sub_top (two-pass transforms), else 0
     int wide_nl = 0;                    // FHE_WIDTH_256: 64-bit limbs per residue in those kernels (2: q < 2^127, 4: q < 2^255)
     bool wide_tiles = true;             // FHE_HIP_NO_WIDE_TILES=1: every stage as a global-memory pass (cross-check / A-B)
     bool no_square = false, single_transforms = false, global_twiddles = false, check_inputs = false, no_fused_keyswitch = false,
@@ -490,14 +491,16 @@ static int create_impl(fhe_rns_ntt **out, uint32_t n, const uint64_t (*moduli)[4
     if (!h) return fail(FHE_ERR_INVALID_ARG, "out of host memory");
     h->n = n; h->L = L; while ((1u << h->log_n) < n) h->log_n++;
     for (uint32_t l = 0; l < L; l++) h->moduli.push_back(cs[l].q);
-    const bool lds_size = h->log_n >= 11 && h->log_n <= 15;
+    // word-sized classes: one LDS-resident kernel per transform for 2^11 .. 2^15 (4-byte residues) / 2^14 (8-byte residues), two passes
+    // (top stages over global memory + 2^13-coefficient LDS blocks) up to 2^16
+    const bool lds_size = h->log_n >= 11 && h->log_n <= 16;
     const char *force = getenv("FHE_HIP_FORCE_WIDTH");       // testing aid: "52" / "64" / "256" force a wider path than needed
     const int floor_w = force ? atoi(force) : 0;
     if (floor_w >= 128) h->width = FHE_WIDTH_256;      // 128: the full-width class on two 64-bit limbs (needs q < 2^127), 256: on four
     else if (lds_size && max_bits <= 30 && floor_w < 52) h->width = FHE_WIDTH_32;
-    else if (lds_size && h->log_n <= 14 && max_bits <= 43 && floor_w < 64) h->width = FHE_WIDTH_52;
-    else if (lds_size && h->log_n <= 14 && max_bits <= 62 && floor_w < 65) h->width = FHE_WIDTH_64;
-    else if (lds_size && h->log_n <= 14 && max_bits <= 64) h->width = FHE_WIDTH_64X;      // FHE_HIP_FORCE_WIDTH=65 forces it
+    else if (lds_size && max_bits <= 43 && floor_w < 64) h->width = FHE_WIDTH_52;
+    else if (lds_size && max_bits <= 62 && floor_w < 65) h->width = FHE_WIDTH_64;
+    else if (lds_size && max_bits <= 64) h->width = FHE_WIDTH_64X;      // FHE_HIP_FORCE_WIDTH=65 forces it
     else h->width = FHE_WIDTH_256;
 #define TRY_OR_DESTROY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { destroy_impl(h); return fail(FHE_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); } } while (0)
     TRY_OR_DESTROY(hipGetDevice(&h->device));
@@ -509,6 +512,7 @@ static int create_impl(fhe_rns_ntt **out, uint32_t n, const uint64_t (*moduli)[4
 #undef TRY_OR_DESTROY
     rc = h->width == FHE_WIDTH_32 ? build_limbs32(h, cs) : h->width == FHE_WIDTH_52 ? build_limbs52(h, cs)
          : h->width == FHE_WIDTH_64 ? build_limbs64(h, cs) : h->width == FHE_WIDTH_64X ? build_limbs64x(h, cs) : build_limbs256(h, cs);
+    if (h->width != FHE_WIDTH_256 && h->log_n > (h->width == FHE_WIDTH_32 ? 15u : 14u)) h->sub_top = h->log_n - 13;
     if (!rc && h->width == FHE_WIDTH_256) {
         h->wide_nl = (max_bits <= 127 && floor_w != 256) ? 2 : 4;
         rc = h->wide_nl == 2 ? build_wlimbs<2>(h, cs) : build_wlimbs<4>(h, cs);
@@ -638,6 +642,31 @@ static int run256_ew(fhe_rns_ntt *h, void *r, const void *a, const void *b, uint
 static int lds_width_id(const fhe_rns_ntt *h) {
     return h->width == FHE_WIDTH_32 ? 32 : h->width == FHE_WIDTH_52 ? 52 : h->width == FHE_WIDTH_64 ? 64 : 65;
 }
+// Two-pass transforms of the word-sized classes (log2 n = 13 + sub_top): one launch of the LOGN = 13 instance per pass.
+static int lds_big(fhe_rns_ntt *h, int op, void *dst, const void *src, const void *src2, uint32_t polys, bool rconst, const char *what) {
+    fhe_dev::lds_launch_fn fn = fhe_dev::lds_lookup(lds_width_id(h), 13);
+    if (!fn) return fail(FHE_ERR_UNSUPPORTED, "no LDS instance for the two-pass transform");
+    const uint32_t chunk_max = (65535u / h->L) * h->L;      // grid.y of the pass kernel; chunks keep the limb phase
+    const size_t poly_bytes = (size_t)h->n * 32;
+    for (uint32_t done = 0; done < polys;) {
+        const uint32_t chunk = polys - done < chunk_max ? polys - done : chunk_max;
+        fhe_dev::LdsArgs A{op, (char *)dst + done * poly_bytes, nullptr, nullptr, (const char *)src + done * poly_bytes, nullptr,
+                           src2 ? (const char *)src2 + done * poly_bytes : nullptr, nullptr, h->d_limbs, h->L, chunk, h->stream};
+        A.top = h->sub_top; A.rconst = rconst;
+        fn(A);
+        done += chunk;
+    }
+    return post_launch(h->stream, what);
+}
+static int big_forward(fhe_rns_ntt *h, void *dst, const void *src, uint32_t polys) {
+    int rc = lds_big(h, fhe_dev::LDS_PASS_FWD, dst, src, nullptr, polys, false, "word_pass_kernel"); if (rc) return rc;
+    return lds_big(h, fhe_dev::LDS_SUB_FORWARD, dst, dst, nullptr, polys, false, "ntt_sub_kernel");
+}
+static int big_inverse(fhe_rns_ntt *h, void *data, uint32_t polys) {
+    int rc = lds_big(h, fhe_dev::LDS_SUB_INVERSE, data, data, nullptr, polys, false, "ntt_sub_kernel"); if (rc) return rc;
+    return lds_big(h, fhe_dev::LDS_PASS_INV, data, data, nullptr, polys, false, "word_pass_kernel");
+}
+
 static int lds_run(fhe_rns_ntt *h, int op, void *r0, void *r1, void *r2, const void *a0, const void *a1, const void *b0,
                    const void *b1, uint32_t polys, const char *what, uint32_t b_polys = 0) {
     fhe_dev::lds_launch_fn fn = fhe_dev::lds_lookup(lds_width_id(h), (int)h->log_n);
@@ -669,12 +698,14 @@ static int lds_check(fhe_rns_ntt *h, const void *d, uint32_t polys) {
 
 static int do_forward(fhe_rns_ntt *h, void *d_data, uint32_t batch) {
     const uint32_t polys = batch * h->L;
+    if (h->sub_top) return big_forward(h, d_data, d_data, polys);
     if (h->width != FHE_WIDTH_256)
         return lds_run(h, fhe_dev::LDS_FORWARD, d_data, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, polys, "ntt_forward_kernel");
     return run256_transform(h, (fhe_dev::u256 *)d_data, polys, true);
 }
 static int do_inverse(fhe_rns_ntt *h, void *d_data, uint32_t batch) {
     const uint32_t polys = batch * h->L;
+    if (h->sub_top) return big_inverse(h, d_data, polys);
     if (h->width != FHE_WIDTH_256)
         return lds_run(h, fhe_dev::LDS_INVERSE, d_data, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, polys, "ntt_inverse_kernel");
     return run256_transform(h, (fhe_dev::u256 *)d_data, polys, false);
@@ -738,6 +769,15 @@ static int do_multiply(fhe_rns_ntt *h, void *d_r, const void *d_a, const void *d
     const uint32_t polys = batch * h->L;
     // d_r may alias d_a and/or d_b, as in the reference (which copies its operands first, src/ntt.cu:50-58): every
     // workgroup loads both of its operand polynomials completely before its first store, and the general path works on copies.
+    if (h->sub_top) {   // two-pass: the top stages of both operands go to the workspace (no copies), one fused launch over the 2^13 blocks, last pass in place
+        const size_t bytes = (size_t)polys * h->n * 32;
+        int rc = ensure_ws(h, 2 * bytes); if (rc) return rc;
+        char *wa = (char *)h->d_ws, *wb = d_b != d_a ? wa + bytes : wa;
+        if ((rc = lds_big(h, fhe_dev::LDS_PASS_FWD, wa, d_a, nullptr, polys, false, "word_pass_kernel"))) return rc;
+        if (d_b != d_a && (rc = lds_big(h, fhe_dev::LDS_PASS_FWD, wb, d_b, nullptr, polys, false, "word_pass_kernel"))) return rc;
+        if ((rc = lds_big(h, fhe_dev::LDS_SUB_MULTIPLY, d_r, wa, wb, polys, false, "ntt_sub_kernel"))) return rc;
+        return lds_big(h, fhe_dev::LDS_PASS_INV, d_r, d_r, nullptr, polys, true, "word_pass_kernel");
+    }
     if (h->width != FHE_WIDTH_256)
         return lds_run(h, fhe_dev::LDS_MULTIPLY, d_r, nullptr, nullptr, d_a, nullptr, d_b, nullptr, polys, "ntt_multiply_kernel");
     return h->wide_nl == 2 ? wide_multiply_t<2>(h, d_r, d_a, d_b, polys) : wide_multiply_t<4>(h, d_r, d_a, d_b, polys);
@@ -745,6 +785,20 @@ static int do_multiply(fhe_rns_ntt *h, void *d_r, const void *d_a, const void *d
 static int do_ct_multiply(fhe_rns_ntt *h, void *c0, void *c1, void *c2, const void *a0, const void *a1, const void *b0,
                           const void *b1, uint32_t batch) {
     const uint32_t polys = batch * h->L;
+    if (h->sub_top) {   // 4 forward transforms into the workspace, NTT-domain products on the field type, 3 inverse transforms
+        const size_t bytes = (size_t)polys * h->n * 32;
+        int rc = ensure_ws(h, 5 * bytes); if (rc) return rc;
+        char *ws = (char *)h->d_ws, *T = ws + 4 * bytes;
+        const void *src[4] = {a0, a1, b0, b1};
+        for (int i = 0; i < 4; i++) if ((rc = big_forward(h, ws + i * bytes, src[i], polys))) return rc;
+        if ((rc = do_ew<0>(h, c0, ws, ws + 2 * bytes, batch, "ct pointwise"))) return rc;
+        if ((rc = do_ew<0>(h, c1, ws, ws + 3 * bytes, batch, "ct pointwise"))) return rc;
+        if ((rc = do_ew<0>(h, T, ws + bytes, ws + 2 * bytes, batch, "ct pointwise"))) return rc;
+        if ((rc = do_ew<1>(h, c1, c1, T, batch, "ct add"))) return rc;
+        if ((rc = do_ew<0>(h, c2, ws + bytes, ws + 3 * bytes, batch, "ct pointwise"))) return rc;
+        for (void *c : {c0, c1, c2}) if ((rc = big_inverse(h, c, polys))) return rc;
+        return FHE_OK;
+    }
     if (h->width != FHE_WIDTH_256)
         return lds_run(h, fhe_dev::LDS_CT_MULTIPLY, c0, c1, c2, a0, a1, b0, b1, polys, "ntt_ct_multiply_kernel");
     return h->wide_nl == 2 ? wide_ct_multiply_t<2>(h, c0, c1, c2, a0, a1, b0, b1, polys) : wide_ct_multiply_t<4>(h, c0, c1, c2, a0, a1, b0, b1, polys);
@@ -790,7 +844,7 @@ extern "C" int fhe_rns_ntt_multiply_bcast(fhe_rns_ntt_t *h, void *r, const void 
     int rc = check_call(h, batch, "multiply_bcast"); if (rc) return rc;
     if (!r || !a || !b_one) return fail(FHE_ERR_INVALID_ARG, "multiply_bcast: null argument");
     if (r == b_one) return fail(FHE_ERR_INVALID_ARG, "multiply_bcast: the result must not overwrite the shared operand");
-    if (h->width != FHE_WIDTH_256)   // every workgroup reads limb (p % L) of the one shared polynomial: L2 hits after the first use
+    if (h->width != FHE_WIDTH_256 && !h->sub_top)   // every workgroup reads limb (p % L) of the one shared polynomial: L2 hits after the first use
         return lds_run(h, fhe_dev::LDS_MULTIPLY, r, nullptr, nullptr, a, nullptr, b_one, nullptr, batch * h->L, "ntt_multiply_kernel", h->L);
     const size_t S = (size_t)h->L * h->n * 32;
     for (uint32_t i = 0; i < batch; i++)
@@ -936,7 +990,7 @@ extern "C" int fhe_relin_keys_create(fhe_rns_ntt_t *h, fhe_relin_keys_t **out, u
         for (const U256 &q : h->moduli) { fhe_host::u128 v = q.w[0]; q_min = v < q_min ? v : q_min; q_max = v > q_max ? v : q_max; }
         digits_fit = (decomp_bits >= 64 ? q_max : (((fhe_host::u128)1 << decomp_bits) < q_max ? ((fhe_host::u128)1 << decomp_bits) : q_max)) <= q_min;
     }
-    if (!rc && h->width != FHE_WIDTH_256 && digits_fit && !h->no_fused_keyswitch) {
+    if (!rc && h->width != FHE_WIDTH_256 && !h->sub_top && digits_fit && !h->no_fused_keyswitch) {
         rc = pack_relin_keys(h, rk);
         if (!rc) {   // the fused kernels read only the packed tables (n * sizeof(E) bytes per key polynomial instead of n * 32): drop the
                      // container copy, so that a bootstrapping key of several hundred RGSW ciphertexts fits (hipFree waits for the packing)

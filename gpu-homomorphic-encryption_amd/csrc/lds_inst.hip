@@ -14,7 +14,34 @@ void CAT(lds_launch_, FHE_FIELD, FHE_LOGN)(const LdsArgs &A) {
     constexpr int MULT_MINW = F::MULT_MINW;
     const dim3 grid(A.polys), block(NttCfg<LOGN>::T);
     const Limb<F> *limbs = (const Limb<F> *)A.limbs;
+    if constexpr (LOGN == 13) {          // this instance also serves N = 2^14 .. 2^16 in two passes (ntt_sub_kernel / word_pass_kernel)
+        using V = typename F::V16;
+        const dim3 pgrid((1u << (13 + A.top)) >> (A.top ? A.top : 1) >> 8, A.polys), sgrid(A.polys << A.top);
+        switch (A.op) {
+            case LDS_PASS_FWD:
+                if (A.top == 3) hipLaunchKernelGGL((word_pass_kernel<F, 3, true>), pgrid, dim3(256), 0, A.stream, (V *)A.r0, (const V *)A.a0, limbs, A.L, 16u, 0u);
+                else if (A.top == 2) hipLaunchKernelGGL((word_pass_kernel<F, 2, true>), pgrid, dim3(256), 0, A.stream, (V *)A.r0, (const V *)A.a0, limbs, A.L, 15u, 0u);
+                else hipLaunchKernelGGL((word_pass_kernel<F, 1, true>), pgrid, dim3(256), 0, A.stream, (V *)A.r0, (const V *)A.a0, limbs, A.L, 14u, 0u);
+                return;
+            case LDS_PASS_INV:
+                if (A.top == 3) hipLaunchKernelGGL((word_pass_kernel<F, 3, false>), pgrid, dim3(256), 0, A.stream, (V *)A.r0, (const V *)A.a0, limbs, A.L, 16u, A.rconst ? 1u : 0u);
+                else if (A.top == 2) hipLaunchKernelGGL((word_pass_kernel<F, 2, false>), pgrid, dim3(256), 0, A.stream, (V *)A.r0, (const V *)A.a0, limbs, A.L, 15u, A.rconst ? 1u : 0u);
+                else hipLaunchKernelGGL((word_pass_kernel<F, 1, false>), pgrid, dim3(256), 0, A.stream, (V *)A.r0, (const V *)A.a0, limbs, A.L, 14u, A.rconst ? 1u : 0u);
+                return;
+            case LDS_SUB_FORWARD:
+                hipLaunchKernelGGL((ntt_sub_kernel<F, 13, SUB_FORWARD, MULT_MINW>), sgrid, block, 0, A.stream, (char *)A.r0, (const char *)A.a0, (const char *)nullptr, limbs, A.L, A.top);
+                return;
+            case LDS_SUB_INVERSE:
+                hipLaunchKernelGGL((ntt_sub_kernel<F, 13, SUB_INVERSE, MULT_MINW>), sgrid, block, 0, A.stream, (char *)A.r0, (const char *)A.a0, (const char *)nullptr, limbs, A.L, A.top);
+                return;
+            case LDS_SUB_MULTIPLY:
+                hipLaunchKernelGGL((ntt_sub_kernel<F, 13, SUB_MULTIPLY, MULT_MINW>), sgrid, block, 0, A.stream, (char *)A.r0, (const char *)A.a0, (const char *)A.b0, limbs, A.L, A.top);
+                return;
+            default: break;
+        }
+    }
     switch (A.op) {
+        default: break;
         case LDS_FORWARD:
             hipLaunchKernelGGL((ntt_forward_kernel<F, LOGN>), grid, block, 0, A.stream, (char *)A.r0, limbs, A.L);
             break;

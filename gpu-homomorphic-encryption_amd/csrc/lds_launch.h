@@ -6,7 +6,10 @@
 
 namespace fhe_dev {
 
-enum LdsOp { LDS_FORWARD = 0, LDS_INVERSE = 1, LDS_MULTIPLY = 2, LDS_CT_MULTIPLY = 3, LDS_KEYSWITCH = 4, LDS_EXTPROD = 5 };
+enum LdsOp { LDS_FORWARD = 0, LDS_INVERSE = 1, LDS_MULTIPLY = 2, LDS_CT_MULTIPLY = 3, LDS_KEYSWITCH = 4, LDS_EXTPROD = 5,
+             // transforms beyond the LDS range (N = 2^(13 + top), top = 1..3; served by the LOGN = 13 instances): the register-only pass over
+             // the top stages (r0 = dst, a0 = src) and the sub-transforms of the 2^top blocks (r0 = dst, a0 = src, b0 = second operand)
+             LDS_PASS_FWD = 6, LDS_PASS_INV = 7, LDS_SUB_FORWARD = 8, LDS_SUB_INVERSE = 9, LDS_SUB_MULTIPLY = 10 };
 
 // true when the instance runs the tensor product as one fused launch; otherwise LDS_CT_MULTIPLY issues
 // multiply(c0), multiply(c2) and the two-product kernel for c1 (three launches, 11*S instead of 7*S bytes)
@@ -45,6 +48,8 @@ struct LdsArgs {
     bool single_transforms = false;      // testing aid (FHE_HIP_NO_PAIRED_TRANSFORMS=1): one digit transform at a time
     uint32_t b_polys = 0;                // LDS_MULTIPLY: polynomials behind b0 (0 = as many as the batch; L = one RNS polynomial broadcast over the batch)
     bool square = false;                 // LDS_MULTIPLY: b0 == a0; LDS_CT_MULTIPLY: (b0, b1) == (a0, a1) -- the squaring forms of the kernels
+    uint32_t top = 0;                    // LDS_PASS_* / LDS_SUB_*: number of stages above the 2^13 blocks (log2 n = 13 + top)
+    bool rconst = false;                 // LDS_PASS_INV: scale with the constants that also absorb the 2^-W of a fused pointwise product
 };
 
 typedef void (*lds_launch_fn)(const LdsArgs &);

@@ -99,7 +99,7 @@ ntt256_inv_pass(u256 *__restrict__ data, const Limb256 *__restrict__ limbs, uint
 // (= mont(mont(a,b), R^2)); 1: add_mod; 2: sub_mod; 3: literal mul_mod_montgomery(a, b) (rns_mul_kernel).
 template <int OP>
 __global__ void __launch_bounds__(256)
-ew256_rns_kernel(u256 *__restrict__ r, const u256 *__restrict__ a, const u256 *__restrict__ b,
+ew256_rns_kernel(u256 *r, const u256 *a, const u256 *b,              // no __restrict__: r may be a or b (in-place add / sub / product)
                  const Limb256 *__restrict__ limbs, uint32_t L, uint32_t log_n, size_t count) {
     size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < count; g += stride) {
@@ -120,7 +120,7 @@ ew256_rns_kernel(u256 *__restrict__ r, const u256 *__restrict__ a, const u256 *_
 // OP 0: mont(a,b); 1: add; 2: sub; 3: mont(a, scalar)
 template <int OP>
 __global__ void __launch_bounds__(256)
-ew256_kernel(u256 *__restrict__ r, const u256 *__restrict__ a, const u256 *__restrict__ b,
+ew256_kernel(u256 *r, const u256 *a, const u256 *b,                  // no __restrict__: callers pass r == a (in-place mul_scalar, add_rns(acc, acc, tmp))
              const u256 q, const u256 scalar, uint64_t inv0, size_t count) {
     size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < count; g += stride) {

@@ -411,14 +411,18 @@ __device__ __forceinline__ void stage_twiddles(typename F::TW *twl, const typena
 // Forward (Cooley-Tukey, merged psi twiddles): stage on index bit b uses twiddle tw[m + (i >> (b+1))], m = N >> (b+1).
 // Processes r-bits KHI down to KLO of pattern Pat.  Values stay in [0, 4q).
 // TWL: `tw` is an LDS copy in the permuted order (non-uniform patterns only).
-template <class F, int LOGN, class Pat, int KHI, int KLO, bool TWL = false>
-__device__ __forceinline__ void fwd_stages(typename F::E (&x)[32], uint32_t tid, const typename F::TW *__restrict__ tw, const Limb<F> &P) {
+// SUB: the 2^LOGN coefficients are block number (pre - 2^k) of a larger transform of 2^(LOGN + k) coefficients whose top k stages
+// ran elsewhere (word_pass_kernel); the stage on local bit b then uses the big table at (pre << (LOGN-1-b)) + (i >> (b+1)), which for
+// pre = 1 is the whole-transform formula.
+template <class F, int LOGN, class Pat, int KHI, int KLO, bool TWL = false, bool SUB = false>
+__device__ __forceinline__ void fwd_stages(typename F::E (&x)[32], uint32_t tid, const typename F::TW *__restrict__ tw, const Limb<F> &P, uint32_t pre = 1) {
     static_assert(!(TWL && Pat::TW_UNIFORM), "uniform stages read device memory");
+    static_assert(!(TWL && SUB), "sub-transforms read their twiddles from device memory");
     const uint32_t base = TWL ? Pat::tw_thread(tid) : Pat::TW_UNIFORM ? 0u : Pat::base(tid);   // uniform -> scalar twiddle loads
 #pragma unroll
     for (int k = KHI; k >= KLO; k--) {
         const int b = Pat::BIT0 + k;
-        const typename F::TW *p = tw + ((1u << (LOGN - 1 - b)) + (TWL ? base : (base >> (b + 1))));
+        const typename F::TW *p = tw + (((SUB ? pre : 1u) << (LOGN - 1 - b)) + (TWL ? base : (base >> (b + 1))));
 #pragma unroll
         for (int r = 0; r < 32; r++) {
             if (r & (1 << k)) continue;
@@ -429,14 +433,15 @@ __device__ __forceinline__ void fwd_stages(typename F::E (&x)[32], uint32_t tid,
 }
 // Inverse (Gentleman-Sande): stage on index bit b uses itw[m + (i >> (b+1))].  Processes r-bits KLO up to KHI.
 // Values stay in [0, 2q).
-template <class F, int LOGN, class Pat, int KLO, int KHI, bool TWL = false>
-__device__ __forceinline__ void inv_stages(typename F::E (&x)[32], uint32_t tid, const typename F::TW *__restrict__ itw, const Limb<F> &P) {
+template <class F, int LOGN, class Pat, int KLO, int KHI, bool TWL = false, bool SUB = false>
+__device__ __forceinline__ void inv_stages(typename F::E (&x)[32], uint32_t tid, const typename F::TW *__restrict__ itw, const Limb<F> &P, uint32_t pre = 1) {
     static_assert(!(TWL && Pat::TW_UNIFORM), "uniform stages read device memory");
+    static_assert(!(TWL && SUB), "sub-transforms read their twiddles from device memory");
     const uint32_t base = TWL ? Pat::tw_thread(tid) : Pat::TW_UNIFORM ? 0u : Pat::base(tid);
 #pragma unroll
     for (int k = KLO; k <= KHI; k++) {
         const int b = Pat::BIT0 + k;
-        const typename F::TW *p = itw + ((1u << (LOGN - 1 - b)) + (TWL ? base : (base >> (b + 1))));
+        const typename F::TW *p = itw + (((SUB ? pre : 1u) << (LOGN - 1 - b)) + (TWL ? base : (base >> (b + 1))));
 #pragma unroll
         for (int r = 0; r < 32; r++) {
             if (r & (1 << k)) continue;
@@ -484,21 +489,21 @@ __device__ __forceinline__ void store_from_lds(char *__restrict__ poly, const ty
 // PRESYNC: the barrier that protects the exchange buffer from the PREVIOUS transform's last reads sits here, after the
 // register-only first group, instead of at the end of the caller's loop body: the latest legal place, where it coincides with
 // the transform's own first barrier (a wave that is ahead keeps computing instead of waiting early).
-template <class F, int LOGN, bool TWL = false, bool PRESYNC = false>
+template <class F, int LOGN, bool TWL = false, bool PRESYNC = false, bool SUB = false>
 __device__ __forceinline__ void fwd_core(typename F::E (&x)[32], typename F::E *lds, uint32_t tid, const Limb<F> &P,
-                                         const typename F::TW *twl = nullptr) {
+                                         const typename F::TW *twl = nullptr, uint32_t pre = 1) {
     using C = NttCfg<LOGN>;
     const typename F::TW *t2 = TWL ? twl : P.tw;
-    fwd_stages<F, LOGN, PatA<LOGN>, 4, 0>(x, tid, P.tw, P);
+    fwd_stages<F, LOGN, PatA<LOGN>, 4, 0, false, SUB>(x, tid, P.tw, P, pre);
     if constexpr (PRESYNC) __syncthreads();
     lds_put<PatA<LOGN>>(lds, tid, x);
     __syncthreads();
     lds_get<PatM<LOGN>>(lds, tid, x);
-    fwd_stages<F, LOGN, PatM<LOGN>, 4, 0, TWL>(x, tid, t2, P);
+    fwd_stages<F, LOGN, PatM<LOGN>, 4, 0, TWL, SUB>(x, tid, t2, P, pre);
     lds_put<PatM<LOGN>>(lds, tid, x);          // same slots this thread just read: no barrier needed before
     __syncthreads();
     lds_get<PatZ<LOGN>>(lds, tid, x);
-    fwd_stages<F, LOGN, PatZ<LOGN>, C::REM - 1, 0, TWL>(x, tid, t2, P);
+    fwd_stages<F, LOGN, PatZ<LOGN>, C::REM - 1, 0, TWL, SUB>(x, tid, t2, P, pre);
 }
 // ---- two forward transforms under ONE modulus at once ------------------------------------------------------------------
 // The key-switch and external-product kernels transform many digit polynomials under the same modulus.  Doing two of them
@@ -544,26 +549,31 @@ __device__ __forceinline__ void fwd_core2(typename F::E (&x0)[32], typename F::E
 }
 
 // NTT values in pattern Z, in [0, 2q)  ->  coefficients in pattern A, in [0, 2q), scaled by the (ninv..) constants
-template <class F, int LOGN, bool TWL = false, bool PRESYNC = false>
+template <class F, int LOGN, bool TWL = false, bool PRESYNC = false, bool SUB = false>
 __device__ __forceinline__ void inv_core(typename F::E (&x)[32], typename F::E *lds, uint32_t tid, const Limb<F> &P,
                                          typename F::E ninv, typename F::E ninv_s, typename F::E ninvw, typename F::E ninvw_s,
-                                         const typename F::TW *twl = nullptr) {
+                                         const typename F::TW *twl = nullptr, uint32_t pre = 1) {
     using C = NttCfg<LOGN>;
     const typename F::TW *t2 = TWL ? twl : P.itw;
-    inv_stages<F, LOGN, PatZ<LOGN>, 0, 4, TWL>(x, tid, t2, P);
+    inv_stages<F, LOGN, PatZ<LOGN>, 0, 4, TWL, SUB>(x, tid, t2, P, pre);
     F::regroup(x, P.q, P.qinv);
     if constexpr (PRESYNC) __syncthreads();
     lds_put<PatZ<LOGN>>(lds, tid, x);
     __syncthreads();
     lds_get<PatY<LOGN>>(lds, tid, x);
-    inv_stages<F, LOGN, PatY<LOGN>, 0, 4, TWL>(x, tid, t2, P);
+    inv_stages<F, LOGN, PatY<LOGN>, 0, 4, TWL, SUB>(x, tid, t2, P, pre);
     F::regroup(x, P.q, P.qinv);
     lds_put<PatY<LOGN>>(lds, tid, x);
     __syncthreads();
     lds_get<PatA<LOGN>>(lds, tid, x);
-    // index bits [10, LOGN-1) <-> r-bits [5-REM, 4) ; bit LOGN-1 <-> r-bit 4 is the scaled last stage
-    inv_stages<F, LOGN, PatA<LOGN>, 5 - C::REM, 3>(x, tid, P.itw, P);
-    inv_last_stage<F>(x, P.q, P.q2, ninv, ninv_s, ninvw, ninvw_s);
+    if constexpr (SUB) {   // a block of a larger transform: bit LOGN-1 is an ordinary stage, the scaling belongs to the last pass
+        inv_stages<F, LOGN, PatA<LOGN>, 5 - C::REM, 4, false, true>(x, tid, P.itw, P, pre);
+        F::regroup(x, P.q, P.qinv);
+    } else {
+        // index bits [10, LOGN-1) <-> r-bits [5-REM, 4) ; bit LOGN-1 <-> r-bit 4 is the scaled last stage
+        inv_stages<F, LOGN, PatA<LOGN>, 5 - C::REM, 3>(x, tid, P.itw, P);
+        inv_last_stage<F>(x, P.q, P.q2, ninv, ninv_s, ninvw, ninvw_s);
+    }
 }
 
 // two inverse transforms in lock step (see fwd_core2)
@@ -692,6 +702,98 @@ ntt_multiply_kernel(char *res, const char *a, const char *b,      // no __restri
     store_from_lds<F, LOGN>(res + off, lds, tid);
 }
 
+// ---- transforms larger than the LDS range: N = 2^(LOGN + k), k = 1..3 --------------------------------------------------------------
+// The top k stages (forward) / last k stages (inverse) run as one register-only pass over global memory (word_pass_kernel below);
+// the 2^k blocks of 2^LOGN consecutive coefficients are then independent sub-transforms, each one workgroup of the LDS-resident
+// machinery above with the big transform's twiddles (SUB = true, pre = 2^k + block).  HBM traffic: 4 S per transform, 9 S per fused
+// multiply (top(a) + top(b) into the workspace 4 S, sub-multiply 3 S, last pass 2 S).
+// grid.x = polys << k: workgroup g handles block g & (2^k - 1) of polynomial g >> k.
+enum { SUB_FORWARD = 0, SUB_INVERSE = 1, SUB_MULTIPLY = 2 };
+template <class F, int LOGN, int MODE, int MINW = 1>
+__global__ void __launch_bounds__(NttCfg<LOGN>::T, MINW)
+ntt_sub_kernel(char *res, const char *a, const char *b, const Limb<F> *__restrict__ limbs, uint32_t L, uint32_t k) {
+    using C = NttCfg<LOGN>;
+    using E = typename F::E;
+    __shared__ E lds[C::LDS_ELEMS];
+    const uint32_t tid = threadIdx.x, p = blockIdx.x >> k, blk = blockIdx.x & ((1u << k) - 1), pre = (1u << k) + blk;
+    const Limb<F> P = limbs[p % L];
+    const size_t off = (size_t)blockIdx.x * (C::N * 32);          // polynomial p starts at p << (LOGN + k) containers
+    E x[32];
+    load_A<F, LOGN>(a + off, tid, x);
+    if constexpr (MODE == SUB_FORWARD) {
+        fwd_core<F, LOGN, false, false, true>(x, lds, tid, P, nullptr, pre);
+#pragma unroll
+        for (int r = 0; r < 32; r++) x[r] = F::canon_fwd(x[r], P.q, P.q2, P.qinv);
+        lds_put<PatZ<LOGN>>(lds, tid, x);
+    } else {
+        if constexpr (MODE == SUB_INVERSE) {
+            lds_put<PatA<LOGN>>(lds, tid, x);
+            __syncthreads();
+            lds_get<PatZ<LOGN>>(lds, tid, x);
+        } else {
+            E y[32];
+            load_A<F, LOGN>(b + off, tid, y);
+            fwd_core<F, LOGN, false, false, true>(x, lds, tid, P, nullptr, pre);
+#pragma unroll
+            for (int r = 0; r < 32; r++) x[r] = F::canon_fwd(x[r], P.q, P.q2, P.qinv);
+            __syncthreads();
+            fwd_core<F, LOGN, false, false, true>(y, lds, tid, P, nullptr, pre);
+#pragma unroll
+            for (int r = 0; r < 32; r++) x[r] = F::pw_mul(x[r], y[r], P.q, P.qinv);   // carries 2^-W until the last pass (ninv_r constants)
+        }
+        inv_core<F, LOGN, false, false, true>(x, lds, tid, P, P.ninv, P.ninv_s, P.ninvw, P.ninvw_s, nullptr, pre);
+#pragma unroll
+        for (int r = 0; r < 32; r++) x[r] = F::canon_inv(x[r], P.q);
+        lds_put<PatA<LOGN>>(lds, tid, x);
+    }
+    __syncthreads();
+    store_from_lds<F, LOGN>(res + off, lds, tid);
+}
+
+// One register-only pass over R <= 3 stages of a transform of 2^log_n coefficients on the field type: FWD: the top R stages (index
+// bits log_n-1 .. log_n-R), natural-order canonical input; !FWD: the last R stages (the same bits, ascending) with the n^-1 scaling
+// folded into the final butterfly (rconst: the constants that also absorb the 2^-W of a fused pointwise product).  Canonical
+// residues in and out (full containers), consecutive lanes on consecutive containers.  src may differ from dst.
+template <class F, int R, bool FWD>
+__global__ void __launch_bounds__(256)
+word_pass_kernel(typename F::V16 *dst, const typename F::V16 *src, const Limb<F> *__restrict__ limbs, uint32_t L, uint32_t log_n, uint32_t rconst) {
+    using E = typename F::E;
+    const uint32_t u = blockIdx.x * 256 + threadIdx.x;                       // u < 2^log_n >> R by construction of the grid
+    const uint32_t p = blockIdx.y;
+    const Limb<F> P = limbs[p % L];
+    const uint32_t b_lo = log_n - R;
+    const typename F::V16 *in = src + ((size_t)p << (log_n + 1)); typename F::V16 *out = dst + ((size_t)p << (log_n + 1));
+    E x[1 << R];
+#pragma unroll
+    for (int k = 0; k < (1 << R); k++) x[k] = F::load_low(in + 2 * ((size_t)u + ((size_t)k << b_lo)));
+#pragma unroll
+    for (int j = 0; j < R; j++) {
+        const int pos = FWD ? R - 1 - j : j;                                  // k-bit of this stage; index bit b_lo + pos
+        if (!FWD && pos == R - 1) {                                            // bit log_n-1: single twiddle itw[1], with the scaling
+#pragma unroll
+            for (int k = 0; k < (1 << (R - 1)); k++)
+                F::inv_last(x[k], x[k | (1 << (R - 1))], P.q, P.q2, rconst ? P.ninv_r : P.ninv, rconst ? P.ninv_r_s : P.ninv_s,
+                            rconst ? P.ninvw_r : P.ninvw, rconst ? P.ninvw_r_s : P.ninvw_s);
+            continue;
+        }
+#pragma unroll
+        for (int hh = 0; hh < (1 << (R - 1)); hh++) {
+            const int k = ((hh >> pos) << (pos + 1)) | (hh & ((1 << pos) - 1));
+            // index bit b = b_lo + pos: twiddle (n >> (b+1)) + (i >> (b+1)) = 2^(R-1-pos) + (k >> (pos+1)): independent of the lane
+            const typename F::TW w = (FWD ? P.tw : P.itw)[(1u << (R - 1 - pos)) + (k >> (pos + 1))];
+            if (FWD) F::fwd_bfly(x[k], x[k | (1 << pos)], w, P);
+            else F::inv_bfly(x[k], x[k | (1 << pos)], w, P);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < (1 << R); k++) {
+        const E v = FWD ? F::canon_fwd(x[k], P.q, P.q2, P.qinv) : F::canon_inv(F::regroup1(x[k], P.q, P.qinv), P.q);
+        typename F::V16 *o = out + 2 * ((size_t)u + ((size_t)k << b_lo));
+        __builtin_nontemporal_store(F::pack(v), o);
+        __builtin_nontemporal_store(F::pack((E)0), o + 1);
+    }
+}
+
 // r = a0 (*) b1 + a1 (*) b0 in one launch (the c1 term of the tensor product) for configurations whose four
 // transformed operands do not fit the register file (8-byte residues at N = 2^14): at most three arrays are live.
 // HBM traffic = read 4 polynomials + write 1.
@@ -808,7 +910,7 @@ ntt_ct_multiply_kernel(char *__restrict__ c0, char *__restrict__ c1, char *__res
 // op 0: r = a*b mod q (plain product in the NTT domain); 1: a+b; 2: a-b.
 template <class F, int OP>
 __global__ void __launch_bounds__(256)
-ew_kernel(typename F::V16 *__restrict__ r, const typename F::V16 *__restrict__ a, const typename F::V16 *__restrict__ b,
+ew_kernel(typename F::V16 *r, const typename F::V16 *a, const typename F::V16 *b,      // no __restrict__: r may be a or b (in-place add / sub / product)
           const Limb<F> *__restrict__ limbs, uint32_t L, uint32_t log_n, size_t halves) {
     using E = typename F::E;
     size_t stride = (size_t)gridDim.x * blockDim.x;

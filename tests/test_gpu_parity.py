@@ -84,8 +84,15 @@ CASES = [
     (2048, ("bits", 63, 2), 2, 5),
     (16384, ("bits", 64, 2), 1, 5),
     (4096, ("mix", (64, 1), (50, 1), (63, 1)), 2, 5),   # one wide prime pulls the whole basis onto the full-range path
-    (32768, ("bits", 64, 1), 1, 4),             # beyond the LDS range of 8-byte residues: general path
-    (65536, ("bits", 30, 1), 1, 4),             # larger than LDS: general path
+    # beyond the LDS range (N = 2^16 on 4-byte residues, 2^15 / 2^16 on 8-byte residues): two-pass transforms on the field type
+    (32768, ("bits", 64, 1), 1, 5),
+    (32768, ("bits", 40, 2), 1, 3),
+    (65536, ("bits", 43, 1), 1, 3),
+    (32768, ("bits", 60, 2), 1, 2),
+    (65536, ("bits", 62, 1), 2, 2),
+    (65536, ("bits", 64, 1), 1, 5),
+    (65536, ("bits", 30, 3), 2, 1),
+    (65536, ("bits", 30, 1), 1, 1),             # larger than LDS: two-pass transform
     # full-width class, LDS-staged tiles of 2^11 coefficients (ntt_wide.hip.h): two-limb (q < 2^127) and four-limb residues,
     # one tile per polynomial, 1-3 top stages in one global pass, 4-5 in two
     (2048, ("bits", 120, 2), 2, 4),
@@ -151,7 +158,7 @@ def test_forward_inverse_multiply_match_oracle(eng, oracle, n, spec, batch, widt
 
 
 @pytest.mark.parametrize("n,spec,batch", [(2048, [40961], 2), (8192, ("bits", 30, 4), 2), (4096, ("bits", 60, 2), 1),
-                                          (16384, ("bits", 40, 6), 1), (256, ("bits", 250, 2), 1), (8192, ("bits", 64, 2), 1), (16384, ("bits", 64, 1), 1), (8192, ("bits", 250, 1), 2), (4096, ("bits", 100, 2), 1)])
+                                          (16384, ("bits", 40, 6), 1), (256, ("bits", 250, 2), 1), (8192, ("bits", 64, 2), 1), (16384, ("bits", 64, 1), 1), (8192, ("bits", 250, 1), 2), (4096, ("bits", 100, 2), 1), (65536, ("bits", 30, 2), 1), (32768, ("bits", 40, 2), 1)])
 def test_ct_multiply_matches_oracle(eng, oracle, n, spec, batch):
     """FHEContext::multiply tensor product (src/fhe.cu:199-218)."""
     moduli = _moduli(spec, n)
@@ -337,7 +344,7 @@ def _random_keys(moduli, n, count, seed):
 @pytest.mark.parametrize("n,spec,w,batch", [(2048, [40961], 8, 2), (8192, ("bits", 30, 4), 16, 3), (4096, ("bits", 30, 2), 30, 2),
                                             (4096, ("bits", 40, 3), 20, 2), (2048, ("bits", 60, 2), 32, 1), (256, ("bits", 250, 2), 64, 2),
                                             (1024, [12289], 16, 2), (2048, ("bits", 64, 2), 32, 2), (4096, ("bits", 63, 1), 16, 1),
-                                            (2048, ("mix", (64, 1), (62, 1)), 64, 1)])
+                                            (2048, ("mix", (64, 1), (62, 1)), 64, 1), (65536, ("bits", 30, 2), 16, 1), (32768, ("bits", 40, 1), 20, 2)])
 @pytest.mark.parametrize("single", [False, True])
 def test_relinearize_matches_oracle(eng, oracle, monkeypatch, n, spec, w, batch, single):
     """FHEContext::relinearize semantics (DESIGN.md, N1) on every width class, arbitrary key material; digit transforms two at a
@@ -530,7 +537,7 @@ def test_from_rns_rejects_oversized_basis(eng):
     e.to_rns(buf, out, 1)          # to_rns has no such limit
 
 
-@pytest.mark.parametrize("n,bits,L", [(8192, 30, 2), (4096, 40, 2), (2048, 60, 1), (256, 250, 1), (2048, 64, 2), (2048, 250, 1), (8192, 100, 1)])
+@pytest.mark.parametrize("n,bits,L", [(8192, 30, 2), (4096, 40, 2), (2048, 60, 1), (256, 250, 1), (2048, 64, 2), (2048, 250, 1), (8192, 100, 1), (65536, 30, 1), (32768, 62, 1)])
 def test_in_place_multiply_and_squaring(eng, oracle, n, bits, L):
     """Like the reference (which copies its operands, src/ntt.cu:50-58) the result may alias an operand."""
     moduli = nm.ntt_primes(bits, n, L)
