@@ -16,7 +16,7 @@ void CAT(lds_launch_, FHE_FIELD, FHE_LOGN)(const LdsArgs &A) {
     const Limb<F> *limbs = (const Limb<F> *)A.limbs;
     if constexpr (LOGN == 13) {          // this instance also serves N = 2^14 .. 2^16 in two passes (ntt_sub_kernel / word_pass_kernel)
         using V = typename F::V16;
-        const dim3 pgrid((1u << (13 + A.top)) >> (A.top ? A.top : 1) >> 8, A.polys), sgrid(A.polys << A.top);
+        const dim3 pgrid((2u << 13) >> 8, A.polys), sgrid(A.polys << A.top);   // pass: two lanes per container of a 2^13-container column block
         switch (A.op) {
             case LDS_PASS_FWD:
                 if (A.top == 3) hipLaunchKernelGGL((word_pass_kernel<F, 3, true>), pgrid, dim3(256), 0, A.stream, (V *)A.r0, (const V *)A.a0, limbs, A.L, 16u, 0u);

@@ -753,12 +753,16 @@ ntt_sub_kernel(char *res, const char *a, const char *b, const Limb<F> *__restric
 // One register-only pass over R <= 3 stages of a transform of 2^log_n coefficients on the field type: FWD: the top R stages (index
 // bits log_n-1 .. log_n-R), natural-order canonical input; !FWD: the last R stages (the same bits, ascending) with the n^-1 scaling
 // folded into the final butterfly (rconst: the constants that also absorb the 2^-W of a fused pointwise product).  Canonical
-// residues in and out (full containers), consecutive lanes on consecutive containers.  src may differ from dst.
+// residues in and out (full containers).  src may differ from dst.
+// Lanes work in pairs: lanes 2c and 2c+1 both load the low word of container c (one request) and run the same butterflies; the even
+// lane then stores the value half of each output container and the odd lane the zero half, so a wave instruction writes 1 KiB of
+// consecutive bytes (like store_from_lds) instead of every other 16 bytes of 2 KiB: 5.5 instead of 4.1 TB/s on the pass, whose
+// arithmetic is far from binding (12 butterflies per 8 containers).  grid = (2^(log_n - R + 1) / 256, polys).
 template <class F, int R, bool FWD>
 __global__ void __launch_bounds__(256)
 word_pass_kernel(typename F::V16 *dst, const typename F::V16 *src, const Limb<F> *__restrict__ limbs, uint32_t L, uint32_t log_n, uint32_t rconst) {
     using E = typename F::E;
-    const uint32_t u = blockIdx.x * 256 + threadIdx.x;                       // u < 2^log_n >> R by construction of the grid
+    const uint32_t g = blockIdx.x * 256 + threadIdx.x, u = g >> 1, half = g & 1;    // u < 2^log_n >> R by construction of the grid
     const uint32_t p = blockIdx.y;
     const Limb<F> P = limbs[p % L];
     const uint32_t b_lo = log_n - R;
@@ -788,9 +792,7 @@ word_pass_kernel(typename F::V16 *dst, const typename F::V16 *src, const Limb<F>
 #pragma unroll
     for (int k = 0; k < (1 << R); k++) {
         const E v = FWD ? F::canon_fwd(x[k], P.q, P.q2, P.qinv) : F::canon_inv(F::regroup1(x[k], P.q, P.qinv), P.q);
-        typename F::V16 *o = out + 2 * ((size_t)u + ((size_t)k << b_lo));
-        __builtin_nontemporal_store(F::pack(v), o);
-        __builtin_nontemporal_store(F::pack((E)0), o + 1);
+        __builtin_nontemporal_store(F::pack(half ? (E)0 : v), out + 2 * ((size_t)u + ((size_t)k << b_lo)) + half);
     }
 }
 
