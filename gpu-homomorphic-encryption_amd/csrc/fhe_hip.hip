@@ -807,6 +807,17 @@ static int do_ct_multiply(fhe_rns_ntt *h, void *c0, void *c1, void *c2, const vo
 // ------------------------------------------------------------------------------------------------------
 // RNS engine ABI
 // ------------------------------------------------------------------------------------------------------
+// FHE_HIP_CHECK_INPUTS=1 (read at engine creation): every compute entry point first scans its operands for coefficients that are not
+// canonical residues (value >= q_l or non-zero upper words) and returns FHE_ERR_NONCANONICAL instead of computing on them -- the
+// word-sized classes read only the low word(s) of a container, so such an operand would otherwise give a silently different
+// product than the reference's full 256-bit arithmetic.  Debugging aid: one extra read of every operand and a stream sync per call.
+extern "C" int fhe_rns_check_canonical(fhe_rns_ntt_t *h, const void *d_data, uint32_t batch);
+static int check_inputs(fhe_rns_ntt *h, std::initializer_list<const void *> operands, uint32_t batch) {
+    if (!h->check_inputs) return FHE_OK;
+    for (const void *p : operands) { int rc = fhe_rns_check_canonical(h, p, batch); if (rc) return rc; }
+    return FHE_OK;
+}
+
 extern "C" int fhe_rns_ntt_create(fhe_rns_ntt_t **out, uint32_t n, const uint64_t (*moduli)[4], uint32_t num_primes) {
     return create_impl(out, n, moduli, num_primes);
 }
@@ -823,11 +834,13 @@ extern "C" int fhe_rns_ntt_width_class(const fhe_rns_ntt_t *h) { return h ? h->w
 extern "C" int fhe_rns_ntt_forward(fhe_rns_ntt_t *h, void *d_data, uint32_t batch) {
     int rc = check_call(h, batch, "forward"); if (rc) return rc;
     if (!d_data) return fail(FHE_ERR_INVALID_ARG, "forward: null data");
+    if ((rc = check_inputs(h, {d_data}, batch))) return rc;
     return do_forward(h, d_data, batch);
 }
 extern "C" int fhe_rns_ntt_inverse(fhe_rns_ntt_t *h, void *d_data, uint32_t batch) {
     int rc = check_call(h, batch, "inverse"); if (rc) return rc;
     if (!d_data) return fail(FHE_ERR_INVALID_ARG, "inverse: null data");
+    if ((rc = check_inputs(h, {d_data}, batch))) return rc;
     return do_inverse(h, d_data, batch);
 }
 extern "C" int fhe_rns_ntt_pointwise(fhe_rns_ntt_t *h, void *r, const void *a, const void *b, uint32_t batch) {
@@ -838,6 +851,7 @@ extern "C" int fhe_rns_ntt_pointwise(fhe_rns_ntt_t *h, void *r, const void *a, c
 extern "C" int fhe_rns_ntt_multiply(fhe_rns_ntt_t *h, void *r, const void *a, const void *b, uint32_t batch) {
     int rc = check_call(h, batch, "multiply"); if (rc) return rc;
     if (!r || !a || !b) return fail(FHE_ERR_INVALID_ARG, "multiply: null argument");
+    if ((rc = check_inputs(h, {a, b}, batch))) return rc;
     return do_multiply(h, r, a, b, batch);
 }
 extern "C" int fhe_rns_ntt_multiply_bcast(fhe_rns_ntt_t *h, void *r, const void *a, const void *b_one, uint32_t batch) {
@@ -875,6 +889,7 @@ extern "C" int fhe_ct_multiply(fhe_rns_ntt_t *h, void *c0, void *c1, void *c2, c
     const void *ins[4] = {a0, a1, b0, b1}; void *outs[3] = {c0, c1, c2};
     for (void *o : outs) for (const void *i : ins) if (o == i) return fail(FHE_ERR_INVALID_ARG, "ct_multiply: outputs must not alias inputs");
     if (c0 == c1 || c0 == c2 || c1 == c2) return fail(FHE_ERR_INVALID_ARG, "ct_multiply: outputs must be distinct");
+    if ((rc = check_inputs(h, {a0, a1, b0, b1}, batch))) return rc;
     return do_ct_multiply(h, c0, c1, c2, a0, a1, b0, b1, batch);
 }
 extern "C" int fhe_rns_check_canonical(fhe_rns_ntt_t *h, const void *d_data, uint32_t batch) {
@@ -1042,6 +1057,7 @@ extern "C" int fhe_ct_relinearize(fhe_rns_ntt_t *h, const fhe_relin_keys_t *rk, 
     if (!rk || !d_c0 || !d_c1 || !d_c2) return fail(FHE_ERR_INVALID_ARG, "ct_relinearize: null argument");
     if (rk->owner != h) return fail(FHE_ERR_INVALID_ARG, "ct_relinearize: keys were imported for a different engine");
     if (d_c0 == d_c1 || d_c0 == d_c2 || d_c1 == d_c2) return fail(FHE_ERR_INVALID_ARG, "ct_relinearize: components must be distinct buffers");
+    if ((rc = check_inputs(h, {d_c0, d_c1, d_c2}, batch))) return rc;
     if (rk->d_pkb) {   // word-sized paths: one fused launch
         fhe_dev::lds_launch_fn fn = fhe_dev::lds_lookup(lds_width_id(h), (int)h->log_n);
         if (!fn) return fail(FHE_ERR_UNSUPPORTED, "transform size outside the LDS-resident range");
@@ -1375,6 +1391,7 @@ extern "C" int fhe_blind_rotate(fhe_rns_ntt_t *h, const fhe_relin_keys_t *const 
         for (int x = 0; x < 4; x++) for (int y = x + 1; y < 4; y++)
             if (bufs[x] == bufs[y]) return fail(FHE_ERR_INVALID_ARG, "blind_rotate: accumulators and scratch must be distinct buffers");
     }
+    if ((rc = check_inputs(h, {d_acc0, d_acc1}, batch))) return rc;
     bool fused = h->width != FHE_WIDTH_256 && !h->no_fused_blind_rotate;
     for (uint32_t s = 0; s < steps; s++) {
         if ((rc = check_rows(h, rows_c0[s], rows_c1[s]))) return rc;

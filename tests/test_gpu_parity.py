@@ -1168,3 +1168,32 @@ def test_multiply_by_one_shared_polynomial(eng, oracle, n, spec, batch):
     assert np.array_equal(dA.download(a.shape), want)
     with pytest.raises(eng.FheError):
         e.multiply_bcast(dB, dA, dB, 1)                        # the shared operand must survive
+
+
+@pytest.mark.parametrize("bits,L", [(30, 2), (40, 2), (60, 1), (64, 1), (250, 1)])
+def test_check_inputs_switch_rejects_noncanonical_operands(eng, monkeypatch, bits, L):
+    """FHE_HIP_CHECK_INPUTS=1 (read at engine creation): the compute entry points scan their operands first and return
+    FHE_ERR_NONCANONICAL for a value >= q or (word-sized classes) a non-zero upper word, instead of a silently different product."""
+    n = 2048; moduli = nm.ntt_primes(bits, n, L)
+    monkeypatch.setenv("FHE_HIP_CHECK_INPUTS", "1")
+    e = eng.RnsNttEngine(n, moduli)
+    a = rns_poly(5, moduli, n, 1); b = rns_poly(6, moduli, n, 1)
+    dA, dB, dR = _up(eng, a), _up(eng, b), eng.DeviceBuffer(a.nbytes)
+    e.multiply(dR, dA, dB, 1)                                    # clean operands pass
+    bad = a.copy(); q = moduli[L - 1]
+    for k in range(4):
+        bad[0, L - 1, 7, k] = (q >> (64 * k)) & 0xFFFFFFFFFFFFFFFF      # coefficient == q
+    cases = [bad]
+    if bits <= 64:
+        up = a.copy(); up[0, 0, 100, 2] = 1                     # non-zero upper word: invisible to the word-sized kernels
+        cases.append(up)
+    for arr in cases:
+        dBad = _up(eng, arr)
+        for call in (lambda: e.multiply(dR, dBad, dB, 1), lambda: e.multiply(dR, dA, dBad, 1), lambda: e.forward(dBad, 1),
+                     lambda: e.ct_multiply(dR, eng.DeviceBuffer(a.nbytes), eng.DeviceBuffer(a.nbytes), dA, dBad, dB, dA, 1)):
+            with pytest.raises(eng.FheError) as ei:
+                call()
+            assert ei.value.code == -6
+    monkeypatch.delenv("FHE_HIP_CHECK_INPUTS")
+    e2 = eng.RnsNttEngine(n, moduli)                             # without the switch the same call runs (garbage in, garbage out)
+    e2.multiply(dR, _up(eng, cases[0]), dB, 1)
