@@ -14,12 +14,24 @@ run --steps 10 --warmup 2 --op fwdinv   --batch 4096
 # configs[2]: ciphertext multiply (tensor product, relinearisation, both), N = 8192, log_q = 120
 run --steps 10 --warmup 2 --op ct       --batch 1024
 run --steps 10 --warmup 2 --op relin    --batch 1024
+run --steps 10 --warmup 2 --op relin    --batch 1024 --decomp-bits 30
+run --steps 10 --warmup 2 --op ctrelin  --batch 1024 --decomp-bits 30
+run --steps 10 --warmup 2 --op ctrelin  --batch 256
+run --steps 20 --warmup 3 --op ctrelin  --batch 1
 run --steps 10 --warmup 2 --op ctrelin  --batch 1024
 # configs[3] shape on one GPU: N = 16384, 6 limbs (30-bit and 40-bit bases), 128 ciphertexts = 1024 / 8
 run --steps 10 --warmup 2 --op multiply --batch 1024 --n 16384 --limbs 6 --bits 30
 run --steps 10 --warmup 2 --op ctrelin  --batch 128 --n 16384 --limbs 6 --bits 30
 run --steps 10 --warmup 2 --op ct       --batch 128 --n 16384 --limbs 6 --bits 40
 run --steps 5  --warmup 1 --op ctrelin  --batch 128 --n 16384 --limbs 6 --bits 40
+run --steps 5  --warmup 1 --op blindrotate --batch 1024
+run --steps 5  --warmup 1 --op blindrotate --batch 128 --n 16384 --limbs 6
+run --steps 5  --warmup 1 --op blindrotate --batch 128 --n 16384 --limbs 6 --decomp-bits 30
+# transforms beyond the LDS range (two-pass, word-sized classes)
+run --steps 5  --warmup 1 --op fwdinv   --batch 512 --n 65536 --limbs 4 --bits 30
+run --steps 5  --warmup 1 --op multiply --batch 512 --n 65536 --limbs 4 --bits 30
+run --steps 5  --warmup 1 --op fwdinv   --batch 512 --n 32768 --limbs 3 --bits 40
+run --steps 5  --warmup 1 --op multiply --batch 512 --n 32768 --limbs 3 --bits 40
 # modulus-width variants of configs[1]/[2]
 run --steps 10 --warmup 2 --op multiply --batch 1024 --bits 40 --limbs 3
 run --steps 10 --warmup 2 --op fwdinv   --batch 1024 --bits 40 --limbs 3
