@@ -54,6 +54,8 @@ def parse():
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak (default, the driver's contract): every rank processes --batch units; strong: --batch is the TOTAL, split into "
                          "contiguous per-rank blocks (sharding.shard_range)")
+    ap.add_argument("--two-calls", action="store_true",
+                    help="ctrelin: fhe_ct_multiply followed by fhe_ct_relinearize (c2 through a container buffer) instead of the one-call fhe_ct_multiply_relin")
     ap.add_argument("--no-verify", action="store_true", help="skip the per-rank result checksum / oracle spot check (outside the timed region)")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the extra legs (op multiply only): batched forward+inverse NTT pairs (the figure the north-star's >= 60 %% target is stated on) "
@@ -343,11 +345,15 @@ def main():
             unit, units_per_poly_bytes, kernel = "relin/s", 5, "ntt_keyswitch"
             what = f"relinearisation: key switching of c2 into (c0, c1), w = {args.decomp_bits}, {L * K} key levels"
         else:
-            def step():
-                eng.ct_multiply(outs[0], outs[1], outs[2], ins[0], ins[1], ins[2], ins[3], B)
-                eng.relinearize(rk, outs[0], outs[1], outs[2], B)
+            if args.two_calls:
+                def step():
+                    eng.ct_multiply(outs[0], outs[1], outs[2], ins[0], ins[1], ins[2], ins[3], B)
+                    eng.relinearize(rk, outs[0], outs[1], outs[2], B)
+            else:            # FHEContext::multiply as one ABI call: c2 stays in the library's (compact) workspace
+                step = lambda: eng.ct_multiply_relin(rk, outs[0], outs[1], ins[0], ins[1], ins[2], ins[3], B)
             unit, units_per_poly_bytes, kernel = "ct-mul/s", 12, "ntt_ct_multiply_kernel+ntt_keyswitch"
-            what = f"full ciphertext multiply: tensor product (7*S) + relinearisation (5*S), w = {args.decomp_bits}"
+            what = (f"full ciphertext multiply ({'fhe_ct_multiply + fhe_ct_relinearize' if args.two_calls else 'fhe_ct_multiply_relin'}): "
+                    f"tensor product (7*S) + relinearisation (5*S), w = {args.decomp_bits}")
 
     def barrier():
         pkg.capi.sync()

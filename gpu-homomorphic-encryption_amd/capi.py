@@ -100,6 +100,7 @@ def lib():
         "fhe_relin_keys_create": ([vp, P(vp), u32, P(vp), P(vp), u32], ci),
         "fhe_relin_keys_destroy": ([vp], ci),
         "fhe_ct_relinearize": ([vp, vp, vp, vp, vp, u32], ci),
+        "fhe_ct_multiply_relin": ([vp, vp, vp, vp, vp, vp, vp, vp, u32], ci),
         "fhe_timer_create": ([P(vp)], ci),
         "fhe_timer_destroy": ([vp], ci),
         "fhe_rns_timer_start": ([vp, vp], ci),
@@ -401,6 +402,10 @@ class RnsNttEngine:
 
     def relinearize(self, rk, d_c0, d_c1, d_c2, batch=1):
         _check(lib().fhe_ct_relinearize(self.h, rk.h, _ptr(d_c0), _ptr(d_c1), _ptr(d_c2), batch))
+
+    def ct_multiply_relin(self, rk, d_c0, d_c1, d_a0, d_a1, d_b0, d_b1, batch=1):
+        """FHEContext::multiply: tensor product + relinearisation in one call (two components out)."""
+        _check(lib().fhe_ct_multiply_relin(self.h, rk.h, _ptr(d_c0), _ptr(d_c1), _ptr(d_a0), _ptr(d_a1), _ptr(d_b0), _ptr(d_b1), batch))
 
     def check_canonical(self, d_data, batch=1):
         _check(lib().fhe_rns_check_canonical(self.h, _ptr(d_data), batch))

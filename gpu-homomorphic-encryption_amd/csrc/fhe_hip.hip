@@ -250,9 +250,10 @@ struct fhe_rns_ntt {
     int wide_nl = 0;                    // FHE_WIDTH_256: 64-bit limbs per residue in those kernels (2: q < 2^127, 4: q < 2^255)
     bool wide_tiles = true;             // FHE_HIP_NO_WIDE_TILES=1: every stage as a global-memory pass (cross-check / A-B)
     bool no_square = false, single_transforms = false, global_twiddles = false, check_inputs = false, no_fused_keyswitch = false,
-         no_word_conversions = false, no_fused_blind_rotate = false;   // environment switches, read once at creation
+         no_word_conversions = false, no_fused_blind_rotate = false, no_fused_ct_relin = false;   // environment switches, read once at creation
     std::vector<void *> d_tables;
     void *d_ws = nullptr; size_t ws_bytes = 0;
+    void *d_ws2 = nullptr; size_t ws2_bytes = 0;   // c2 of the fused multiply + relinearise (compact or containers); separate from d_ws, which the general paths use
     uint32_t *d_flag = nullptr;
     std::vector<U256> moduli;
     void *d_crt = nullptr;               // CrtLimb[L], built on first use of to_rns / from_rns (owned by d_tables)
@@ -275,6 +276,7 @@ static void destroy_impl(fhe_rns_ntt *h) {
     if (!h) return;
     for (void *p : h->d_tables) (void)hipFree(p);
     if (h->d_ws) (void)hipFree(h->d_ws);
+    if (h->d_ws2) (void)hipFree(h->d_ws2);
     if (h->d_cdt) (void)hipFree(h->d_cdt);
     if (h->d_flag) (void)hipFree(h->d_flag);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -525,6 +527,7 @@ static int create_impl(fhe_rns_ntt **out, uint32_t n, const uint64_t (*moduli)[4
     h->no_fused_keyswitch = getenv("FHE_HIP_NO_FUSED_KEYSWITCH") != nullptr;
     h->no_word_conversions = getenv("FHE_HIP_NO_WORD_CONVERSIONS") != nullptr;
     h->no_fused_blind_rotate = getenv("FHE_HIP_NO_FUSED_BLIND_ROTATE") != nullptr;
+    h->no_fused_ct_relin = getenv("FHE_HIP_NO_FUSED_CT_RELIN") != nullptr;
     { const char *e = getenv("FHE_HIP_CHECK_INPUTS"); h->check_inputs = e && e[0] == '1'; }
     *out = h;
     return FHE_OK;
@@ -545,6 +548,15 @@ static int ensure_ws(fhe_rns_ntt *h, size_t bytes) {
     if (h->d_ws) { HIP_TRY(hipFree(h->d_ws)); h->d_ws = nullptr; h->ws_bytes = 0; }
     HIP_TRY(hipMalloc(&h->d_ws, bytes));
     h->ws_bytes = bytes;
+    return FHE_OK;
+}
+
+static int ensure_ws2(fhe_rns_ntt *h, size_t bytes) {
+    if (h->ws2_bytes >= bytes) return FHE_OK;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (h->d_ws2) { HIP_TRY(hipFree(h->d_ws2)); h->d_ws2 = nullptr; h->ws2_bytes = 0; }
+    HIP_TRY(hipMalloc(&h->d_ws2, bytes));
+    h->ws2_bytes = bytes;
     return FHE_OK;
 }
 
@@ -1089,6 +1101,42 @@ extern "C" int fhe_ct_relinearize(fhe_rns_ntt_t *h, const fhe_relin_keys_t *rk, 
         if ((rc = do_ew<1>(h, c1, c1, acc1, nb, "relin add"))) return rc;
     }
     return FHE_OK;
+}
+
+// FHEContext::multiply as the reference declares it (src/fhe.cu:199-224: tensor product, then relinearize): (c0, c1) = relin(a (x) b).
+// Where the tensor-product and the key-switch kernel both exist in their one-launch forms, c2 never takes the 32-byte container
+// form: the tensor product writes it to a compact workspace (sizeof(residue) bytes per coefficient) and the key switch reads it from
+// there -- 2 launches, HBM traffic 4 S in + 2 S out + c2 at S/8 (S/4) per pass instead of 12 S.  Elsewhere: fhe_ct_multiply into a
+// container workspace followed by fhe_ct_relinearize.  Same bits either way (tests compare both with the oracle).
+extern "C" int fhe_ct_multiply_relin(fhe_rns_ntt_t *h, const fhe_relin_keys_t *rk, void *d_c0, void *d_c1, const void *d_a0, const void *d_a1,
+                                     const void *d_b0, const void *d_b1, uint32_t batch) {
+    int rc = check_call(h, batch, "ct_multiply_relin"); if (rc) return rc;
+    if (!rk || !d_c0 || !d_c1 || !d_a0 || !d_a1 || !d_b0 || !d_b1) return fail(FHE_ERR_INVALID_ARG, "ct_multiply_relin: null argument");
+    if (rk->owner != h) return fail(FHE_ERR_INVALID_ARG, "ct_multiply_relin: keys were imported for a different engine");
+    const void *ins[4] = {d_a0, d_a1, d_b0, d_b1};
+    for (const void *i : ins) if (d_c0 == i || d_c1 == i) return fail(FHE_ERR_INVALID_ARG, "ct_multiply_relin: outputs must not alias inputs");
+    if (d_c0 == d_c1) return fail(FHE_ERR_INVALID_ARG, "ct_multiply_relin: outputs must be distinct");
+    if ((rc = check_inputs(h, {d_a0, d_a1, d_b0, d_b1}, batch))) return rc;
+    const int eb = h->width == FHE_WIDTH_32 ? 4 : 8;
+    const bool fused = rk->d_pkb && h->width != FHE_WIDTH_256 && !h->sub_top && !h->single_transforms && !h->no_fused_ct_relin &&
+                       fhe_dev::lds_compact_c2(eb, (int)h->log_n);
+    const uint32_t polys = batch * h->L;
+    if (fused) {
+        if ((rc = ensure_ws2(h, (size_t)polys * h->n * eb))) return rc;
+        fhe_dev::lds_launch_fn fn = fhe_dev::lds_lookup(lds_width_id(h), (int)h->log_n);
+        if (!fn) return fail(FHE_ERR_UNSUPPORTED, "transform size outside the LDS-resident range");
+        fhe_dev::LdsArgs A{fhe_dev::LDS_CT_MULTIPLY, d_c0, d_c1, h->d_ws2, d_a0, d_a1, d_b0, d_b1, h->d_limbs, h->L, polys, h->stream};
+        A.compact_c2 = true;
+        fn(A);
+        if ((rc = post_launch(h->stream, "ntt_ct_multiply_kernel (compact c2)"))) return rc;
+        fhe_dev::LdsArgs B{fhe_dev::LDS_KEYSWITCH, d_c0, d_c1, nullptr, h->d_ws2, nullptr, nullptr, nullptr, h->d_limbs, h->L, polys, h->stream};
+        B.kb = rk->d_pkb; B.ka = rk->d_pka; B.K = rk->K; B.w = rk->decomp_bits; B.compact_c2 = true;
+        fn(B);
+        return post_launch(h->stream, "ntt_keyswitch kernel (compact c2)");
+    }
+    if ((rc = ensure_ws2(h, (size_t)polys * h->n * 32))) return rc;
+    if ((rc = do_ct_multiply(h, d_c0, d_c1, h->d_ws2, d_a0, d_a1, d_b0, d_b1, batch))) return rc;
+    return fhe_ct_relinearize(h, rk, d_c0, d_c1, h->d_ws2, batch);
 }
 
 

@@ -58,7 +58,12 @@ void CAT(lds_launch_, FHE_FIELD, FHE_LOGN)(const LdsArgs &A) {
             break;
         case LDS_CT_MULTIPLY:
             if constexpr (lds_ct_fused(sizeof(typename F::E), LOGN)) {
-                if (A.square)
+                if (A.compact_c2) {
+                    if constexpr (lds_compact_c2(sizeof(typename F::E), LOGN))
+                        hipLaunchKernelGGL((ntt_ct_multiply_kernel<F, LOGN, false, true>), grid, block, 0, A.stream, (char *)A.r0, (char *)A.r1,
+                                           (char *)A.r2, (const char *)A.a0, (const char *)A.a1, (const char *)A.b0, (const char *)A.b1,
+                                           limbs, A.L);
+                } else if (A.square)
                     hipLaunchKernelGGL((ntt_ct_multiply_kernel<F, LOGN, true>), grid, block, 0, A.stream, (char *)A.r0, (char *)A.r1,
                                        (char *)A.r2, (const char *)A.a0, (const char *)A.a1, (const char *)A.b0, (const char *)A.b1,
                                        limbs, A.L);
@@ -77,7 +82,16 @@ void CAT(lds_launch_, FHE_FIELD, FHE_LOGN)(const LdsArgs &A) {
             break;
         case LDS_KEYSWITCH: {
             using E = typename F::E;
-            if constexpr (lds_keyswitch_split(sizeof(E), LOGN)) {
+            if (A.compact_c2) {          // the host sets it only where lds_compact_c2 holds and the default kernels are selected
+                if constexpr (lds_compact_c2(sizeof(E), LOGN)) {
+                    if constexpr (lds_keyswitch_split(sizeof(E), LOGN))
+                        hipLaunchKernelGGL((ntt_keyswitch_kernel<F, LOGN, 2, true, false, true>), dim3(A.polys * 2), block, 0, A.stream, (char *)A.r0, (char *)A.r1,
+                                           (const char *)A.a0, (const E *)A.kb, (const E *)A.ka, limbs, A.L, A.K, A.w);
+                    else
+                        hipLaunchKernelGGL((ntt_keyswitch2_kernel<F, LOGN, 2, true>), grid, block, 0, A.stream, (char *)A.r0, (char *)A.r1,
+                                           (const char *)A.a0, (const E *)A.kb, (const E *)A.ka, limbs, A.L, A.K, A.w);
+                }
+            } else if constexpr (lds_keyswitch_split(sizeof(E), LOGN)) {
                 hipLaunchKernelGGL((ntt_keyswitch_kernel<F, LOGN, 2, true>), dim3(A.polys * 2), block, 0, A.stream, (char *)A.r0, (char *)A.r1,
                                    (const char *)A.a0, (const E *)A.kb, (const E *)A.ka, limbs, A.L, A.K, A.w);
             } else if (lds_paired_keyswitch(sizeof(E), LOGN) && !A.single_transforms) {

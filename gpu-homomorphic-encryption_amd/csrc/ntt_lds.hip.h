@@ -466,6 +466,26 @@ __device__ __forceinline__ void load_A(const char *__restrict__ poly, uint32_t t
 #pragma unroll
     for (int r = 0; r < 32; r++) x[r] = F::load_low(p + (size_t)r * (NttCfg<LOGN>::T * 32));
 }
+// Compact polynomials (internal workspace only, never at the ABI): sizeof(E) bytes per coefficient, natural order.  The fused
+// FHEContext::multiply (tensor product + relinearisation) hands c2 from the tensor-product kernel to the key-switch kernel in this
+// form: c2 is written once as S/8 (S/4 for 8-byte residues) and each of the L limb workgroups that re-read it moves S/8 instead of S.
+template <class F, int LOGN>
+__device__ __forceinline__ void load_A_compact(const typename F::E *__restrict__ poly, uint32_t tid, typename F::E (&x)[32]) {
+#pragma unroll
+    for (int r = 0; r < 32; r++) x[r] = poly[tid + r * NttCfg<LOGN>::T];
+}
+template <class F, int LOGN>
+__device__ __forceinline__ void store_A_compact(typename F::E *__restrict__ poly, uint32_t tid, const typename F::E (&x)[32]) {
+#pragma unroll
+    for (int r = 0; r < 32; r++) poly[tid + r * NttCfg<LOGN>::T] = x[r];
+}
+// source of a key-switch digit polynomial: 32-byte containers (the ABI's c2) or the compact workspace
+template <class F, int LOGN, bool COMPACT>
+__device__ __forceinline__ void load_src(const char *__restrict__ base, size_t poly_index, uint32_t tid, typename F::E (&x)[32]) {
+    if constexpr (COMPACT) load_A_compact<F, LOGN>(reinterpret_cast<const typename F::E *>(base) + poly_index * NttCfg<LOGN>::N, tid, x);
+    else load_A<F, LOGN>(base + poly_index * (NttCfg<LOGN>::N * 32), tid, x);
+}
+
 // Store the whole polynomial from LDS as full containers: consecutive lanes write consecutive 16-byte
 // halves (even lane: {value, 0...}; odd lane: zeros), i.e. 1 KiB contiguous per wave instruction.
 template <class F, int LOGN>
@@ -841,7 +861,8 @@ ntt_mac2_kernel(char *__restrict__ res, const char *__restrict__ a0, const char 
 // HBM traffic = read 4 polynomials + write 3.
 // SQUARE: (b0, b1) is (a0, a1) (the host passes the flag when the operand pointers are equal -- squaring a ciphertext): two loads and
 // two forward transforms instead of four, c1 = 2 a0 a1; 5*S of traffic instead of 7*S.
-template <class F, int LOGN, bool SQUARE = false>
+// COMPACT_C2: c2 goes to the compact workspace (see load_A_compact) instead of a container buffer: the fused multiply + relinearise.
+template <class F, int LOGN, bool SQUARE = false, bool COMPACT_C2 = false>
 __global__ void __launch_bounds__(NttCfg<LOGN>::T)
 ntt_ct_multiply_kernel(char *__restrict__ c0, char *__restrict__ c1, char *__restrict__ c2,
                        const char *__restrict__ a0, const char *__restrict__ a1,
@@ -903,9 +924,13 @@ ntt_ct_multiply_kernel(char *__restrict__ c0, char *__restrict__ c1, char *__res
     inv_core<F, LOGN>(B0, lds, tid, P, P.ninv_r, P.ninv_r_s, P.ninvw_r, P.ninvw_r_s);
 #pragma unroll
     for (int r = 0; r < 32; r++) B0[r] = F::canon_inv(B0[r], P.q);
-    lds_put<PatA<LOGN>>(lds, tid, B0);
-    __syncthreads();
-    store_from_lds<F, LOGN>(c2 + off, lds, tid);
+    if constexpr (COMPACT_C2) {
+        store_A_compact<F, LOGN>(reinterpret_cast<E *>(c2) + (size_t)p * C::N, tid, B0);   // pattern A: consecutive lanes, consecutive words
+    } else {
+        lds_put<PatA<LOGN>>(lds, tid, B0);
+        __syncthreads();
+        store_from_lds<F, LOGN>(c2 + off, lds, tid);
+    }
 }
 
 // Element-wise kernels over [batch][L][n] containers of word-sized residues: one 16-byte half-container per lane.
@@ -978,7 +1003,7 @@ pack_keys_kernel(typename F::E *__restrict__ packed, const typename F::V16 *__re
 // TWL = true: the forward (then the inverse) twiddle table of limb i is copied into LDS once per workgroup; the 2*L*K + 2
 // transforms then take their non-uniform twiddles from LDS (~100 cycles, conflict-free in the permuted order) instead of L2
 // (500+ cycles), which these register-starved kernels (2 waves per SIMD) cannot hide.  N * sizeof(TW) more LDS per workgroup.
-template <class F, int LOGN, int MINW = 1, bool SPLIT = false, bool TWL = false>
+template <class F, int LOGN, int MINW = 1, bool SPLIT = false, bool TWL = false, bool COMPACT = false>
 __global__ void __launch_bounds__(NttCfg<LOGN>::T, MINW)
 ntt_keyswitch_kernel(char *__restrict__ c0, char *__restrict__ c1, const char *__restrict__ c2,
                      const typename F::E *__restrict__ kb, const typename F::E *__restrict__ ka,
@@ -1009,7 +1034,7 @@ ntt_keyswitch_kernel(char *__restrict__ c0, char *__restrict__ c1, const char *_
         for (int r = 0; r < 32; r++) { acc0[r] = 0; acc1[r] = 0; }
         if constexpr (TWL) { stage_twiddles<F, LOGN, true>(twl, P.tw, tid); __syncthreads(); }
         for (uint32_t j = 0; j < L; j++) {
-            load_A<F, LOGN>(c2 + ((size_t)b * L + j) * (C::N * 32), tid, x);
+            load_src<F, LOGN, COMPACT>(c2, (size_t)b * L + j, tid, x);
             for (uint32_t k = 0; k < K; k++) {
 #pragma unroll
                 for (int r = 0; r < 32; r++) d[r] = F::digit(x[r], k * w, w);
@@ -1055,7 +1080,7 @@ ntt_keyswitch_kernel(char *__restrict__ c0, char *__restrict__ c1, const char *_
         for (uint32_t j = 0; j < L; j++) {
             for (uint32_t k = 0; k < K; k++) {
                 // the c2 limb is re-read per digit (L2 / Infinity-Cache hits after the first) rather than held in 64 more VGPRs
-                load_A<F, LOGN>(c2 + ((size_t)b * L + j) * (C::N * 32), tid, d);
+                load_src<F, LOGN, COMPACT>(c2, (size_t)b * L + j, tid, d);
 #pragma unroll
                 for (int r = 0; r < 32; r++) d[r] = F::digit(d[r], k * w, w);
                 fwd_core<F, LOGN, false, true>(d, lds, tid, P);
@@ -1289,7 +1314,7 @@ __device__ __forceinline__ void finish_pair(typename F::E (&acc0)[32], typename 
     store_from_lds<F, LOGN>(dst1, lds1, tid);
 }
 
-template <class F, int LOGN, int MINW = 1>
+template <class F, int LOGN, int MINW = 1, bool COMPACT = false>
 __global__ void __launch_bounds__(NttCfg<LOGN>::T, MINW)
 ntt_keyswitch2_kernel(char *__restrict__ c0, char *__restrict__ c1, const char *__restrict__ c2,
                       const typename F::E *__restrict__ kb, const typename F::E *__restrict__ ka,
@@ -1303,7 +1328,7 @@ ntt_keyswitch2_kernel(char *__restrict__ c0, char *__restrict__ c1, const char *
     else { b = bid / L; i = bid % L; }
     const uint32_t p = b * L + i;
     const Limb<F> P = limbs[i];
-    const char *ct2 = c2 + (size_t)b * L * (C::N * 32);
+    const size_t ct2 = (size_t)b * L;                    // first limb polynomial of this ciphertext's c2
     E acc0[32], acc1[32], d0[32], d1[32];
 #pragma unroll
     for (int r = 0; r < 32; r++) { acc0[r] = 0; acc1[r] = 0; }
@@ -1311,12 +1336,12 @@ ntt_keyswitch2_kernel(char *__restrict__ c0, char *__restrict__ c1, const char *
     uint32_t jk = 0;
     for (; jk + 1 < LK; jk += 2) {
         const uint32_t j0 = jk / K, k0 = jk % K, j1 = (jk + 1) / K, k1 = (jk + 1) % K;
-        load_A<F, LOGN>(ct2 + (size_t)j1 * (C::N * 32), tid, d1);
+        load_src<F, LOGN, COMPACT>(c2, ct2 + j1, tid, d1);
         if (j0 == j1) {
 #pragma unroll
             for (int r = 0; r < 32; r++) d0[r] = F::digit(d1[r], k0 * w, w);
         } else {
-            load_A<F, LOGN>(ct2 + (size_t)j0 * (C::N * 32), tid, d0);
+            load_src<F, LOGN, COMPACT>(c2, ct2 + j0, tid, d0);
 #pragma unroll
             for (int r = 0; r < 32; r++) d0[r] = F::digit(d0[r], k0 * w, w);
         }
@@ -1327,7 +1352,7 @@ ntt_keyswitch2_kernel(char *__restrict__ c0, char *__restrict__ c1, const char *
     }
     if (jk < LK) {                                        // odd number of digit polynomials: the last one alone
         const uint32_t j0 = jk / K, k0 = jk % K;
-        load_A<F, LOGN>(ct2 + (size_t)j0 * (C::N * 32), tid, d0);
+        load_src<F, LOGN, COMPACT>(c2, ct2 + j0, tid, d0);
 #pragma unroll
         for (int r = 0; r < 32; r++) d0[r] = F::digit(d0[r], k0 * w, w);
         fwd_core<F, LOGN, false, true>(d0, lds, tid, P);

@@ -110,14 +110,24 @@ public:
         result.noise_budget = ct.noise_budget; result.level = ct.level;
     }
 
-    // src/fhe.cu:199-224: tensor product in ONE fused launch (4 forward + 3 inverse transforms instead of
-    // the reference's 8 + 4), then relinearize().
+    // src/fhe.cu:199-224: tensor product (4 forward + 3 inverse transforms instead of the reference's 8 + 4), then relinearisation.
+    // With keys the two steps are ONE ABI call (fhe_ct_multiply_relin: c2 never leaves the library's workspace); with an empty
+    // RelinKeys the result keeps its three components, as relinearize() does.
     void multiply(Ciphertext &result, const Ciphertext &a, const Ciphertext &b, const RelinKeys &rlk) {
         if (a.components.size() != 2 || b.components.size() != 2) throw std::runtime_error("FHEContext::multiply: 2-component ciphertexts expected");
-        ensure_components(result, 3);
-        params_.rns_ntt->tensor_multiply(result.components[0]->coeffs, result.components[1]->coeffs, result.components[2]->coeffs,
-                                         a.components[0]->coeffs, a.components[1]->coeffs, b.components[0]->coeffs, b.components[1]->coeffs);
-        relinearize(result, rlk);
+        if (rlk.rlk_keys.empty()) {
+            ensure_components(result, 3);
+            params_.rns_ntt->tensor_multiply(result.components[0]->coeffs, result.components[1]->coeffs, result.components[2]->coeffs,
+                                             a.components[0]->coeffs, a.components[1]->coeffs, b.components[0]->coeffs, b.components[1]->coeffs);
+        } else {
+            import_relin_keys(rlk);
+            ensure_components(result, 2);
+            while (result.components.size() > 2) { delete result.components.back(); result.components.pop_back(); }
+            check(fhe_ct_multiply_relin(params_.rns_ntt->handle(), rlk.imported, result.components[0]->coeffs, result.components[1]->coeffs,
+                                        a.components[0]->coeffs, a.components[1]->coeffs, b.components[0]->coeffs, b.components[1]->coeffs, 1),
+                  "FHEContext::multiply");
+            device_synchronize();
+        }
         result.noise_budget = a.noise_budget + b.noise_budget + 10;   // the reference's rough estimate (src/fhe.cu:222)
         result.level = std::max(a.level, b.level);
     }
@@ -129,19 +139,23 @@ public:
         if (ct.components.size() <= 2) return;                                              // src/fhe.cu:227
         if (rlk.rlk_keys.empty()) return;
         if (ct.components.size() != 3) throw std::runtime_error("FHEContext::relinearize: 3-component ciphertext expected");
-        if (!rlk.imported || rlk.imported_for != params_.rns_ntt) {
-            fhe_relin_keys_destroy(rlk.imported); rlk.imported = nullptr;
-            std::vector<const void *> kb, ka;
-            for (const PublicKey *k : rlk.rlk_keys) { kb.push_back(k->pk0->coeffs); ka.push_back(k->pk1->coeffs); }
-            check(fhe_relin_keys_create(params_.rns_ntt->handle(), &rlk.imported, rlk.decomp_bits, kb.data(), ka.data(), (uint32_t)kb.size()),
-                  "FHEContext::relinearize: key import");
-            rlk.imported_for = params_.rns_ntt;
-        }
+        import_relin_keys(rlk);
         check(fhe_ct_relinearize(params_.rns_ntt->handle(), rlk.imported, ct.components[0]->coeffs, ct.components[1]->coeffs,
                                  ct.components[2]->coeffs, 1), "FHEContext::relinearize");
         device_synchronize();
         delete ct.components[2];
         ct.components.resize(2);                                                            // src/fhe.cu:234
+    }
+
+    // hands the key polynomials to the engine once (transformed and packed inside the library), cached in the RelinKeys object
+    void import_relin_keys(const RelinKeys &rlk) {
+        if (rlk.imported && rlk.imported_for == params_.rns_ntt) return;
+        fhe_relin_keys_destroy(rlk.imported); rlk.imported = nullptr;
+        std::vector<const void *> kb, ka;
+        for (const PublicKey *k : rlk.rlk_keys) { kb.push_back(k->pk0->coeffs); ka.push_back(k->pk1->coeffs); }
+        check(fhe_relin_keys_create(params_.rns_ntt->handle(), &rlk.imported, rlk.decomp_bits, kb.data(), ka.data(), (uint32_t)kb.size()),
+              "FHEContext: relinearisation key import");
+        rlk.imported_for = params_.rns_ntt;
     }
 
     // number of key levels relinkey_gen must produce for this context: L limbs x ceil(bits(q_max) / decomp_bits) digits

@@ -217,6 +217,12 @@ int fhe_relin_keys_destroy(fhe_relin_keys_t *rk);
  * c0 += sum_{j,k} D_{j,k} * b_{j,k},  c1 += sum_{j,k} D_{j,k} * a_{j,k}  with D_{j,k} the digit polynomials of c2.
  * c0, c1 are [batch][L][n] and updated in place; c2 is read only. */
 int fhe_ct_relinearize(fhe_rns_ntt_t *h, const fhe_relin_keys_t *rk, void *d_c0, void *d_c1, const void *d_c2, uint32_t batch);
+/* FHEContext::multiply as declared (include/fhe.cuh:101-103, src/fhe.cu:199-224): tensor product followed by relinearisation,
+ * (c0, c1) = relin(a (x) b), two components out.  Same result as fhe_ct_multiply + fhe_ct_relinearize; c2 stays in an internal
+ * workspace (compact form on the word-sized classes), so the call moves about half the bytes of the two-call sequence.
+ * Outputs must be distinct and must not alias the inputs. */
+int fhe_ct_multiply_relin(fhe_rns_ntt_t *h, const fhe_relin_keys_t *rk, void *d_c0, void *d_c1, const void *d_a0, const void *d_a1,
+                          const void *d_b0, const void *d_b1, uint32_t batch);
 
 /* ---- blind-rotation inner loop ------------------------------------------------------ */
 /* FHEContext::blind_rotate is only declared in the reference (include/fhe.cuh:139; pipeline prose README.md:146-159).  Its

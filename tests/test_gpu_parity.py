@@ -1197,3 +1197,35 @@ def test_check_inputs_switch_rejects_noncanonical_operands(eng, monkeypatch, bit
     monkeypatch.delenv("FHE_HIP_CHECK_INPUTS")
     e2 = eng.RnsNttEngine(n, moduli)                             # without the switch the same call runs (garbage in, garbage out)
     e2.multiply(dR, _up(eng, cases[0]), dB, 1)
+
+
+@pytest.mark.parametrize("n,spec,w,batch", [(8192, ("bits", 30, 4), 16, 3), (16384, ("bits", 30, 3), 30, 2), (2048, [40961], 8, 9),
+                                            (32768, ("bits", 30, 1), 16, 1), (65536, ("bits", 30, 1), 16, 1),      # no fused tensor product / two-pass: composition
+                                            (4096, ("bits", 40, 2), 20, 3), (8192, ("bits", 43, 2), 16, 1), (16384, ("bits", 40, 2), 20, 1),
+                                            (2048, ("bits", 60, 2), 32, 2), (8192, ("bits", 64, 1), 32, 1), (256, ("bits", 250, 1), 64, 2),
+                                            (2048, ("bits", 120, 1), 40, 1)])
+@pytest.mark.parametrize("fused", [True, False])
+def test_ct_multiply_relin_matches_oracle(eng, oracle, monkeypatch, n, spec, w, batch, fused):
+    """FHEContext::multiply as the reference declares it (src/fhe.cu:199-224): tensor product + relinearisation in ONE call.  fused: c2
+    crosses from the tensor-product kernel to the key-switch kernel in the compact workspace where both kernels exist (else, and with
+    FHE_HIP_NO_FUSED_CT_RELIN=1, the two-call composition inside the library); every variant equals oracle ct_multiply + relinearize."""
+    if not fused:
+        monkeypatch.setenv("FHE_HIP_NO_FUSED_CT_RELIN", "1")
+    moduli = _moduli(spec, n); L = len(moduli)
+    e = eng.RnsNttEngine(n, moduli); rp = oracle.RnsPlan(n, moduli)
+    K = e.relin_num_digits(w)
+    kb = _random_keys(moduli, n, L * K, 1100); ka = _random_keys(moduli, n, L * K, 1900)
+    rk = e.import_relin_keys(w, [_up(eng, k) for k in kb], [_up(eng, k) for k in ka])
+    a0, a1, b0, b1 = (rns_poly(s, moduli, n, batch) for s in (61, 62, 63, 64))
+    d = [_up(eng, x) for x in (a0, a1, b0, b1)]
+    c0, c1 = eng.DeviceBuffer(a0.nbytes), eng.DeviceBuffer(a0.nbytes)
+    for rep in range(2):                                         # the second call reuses the workspace
+        e.ct_multiply_relin(rk, c0, c1, d[0], d[1], d[2], d[3], batch)
+    t0, t1, t2 = rp.ct_multiply(a0, a1, b0, b1, threads=8)
+    w0, w1 = rp.relinearize(w, t0, t1, t2, kb, ka, threads=8)
+    assert np.array_equal(c0.download(a0.shape), w0)
+    assert np.array_equal(c1.download(a0.shape), w1)
+    for buf, src in zip(d, (a0, a1, b0, b1)):
+        assert np.array_equal(buf.download(a0.shape), src)
+    with pytest.raises(eng.FheError):
+        e.ct_multiply_relin(rk, d[0], c1, d[0], d[1], d[2], d[3], batch)     # an output aliases an input
