@@ -863,7 +863,7 @@ ntt_mac2_kernel(char *__restrict__ res, const char *__restrict__ a0, const char 
 // two forward transforms instead of four, c1 = 2 a0 a1; 5*S of traffic instead of 7*S.
 // COMPACT_C2: c2 goes to the compact workspace (see load_A_compact) instead of a container buffer: the fused multiply + relinearise.
 template <class F, int LOGN, bool SQUARE = false, bool COMPACT_C2 = false>
-__global__ void __launch_bounds__(NttCfg<LOGN>::T)
+__global__ void __launch_bounds__(NttCfg<LOGN>::T, (sizeof(typename F::E) == 8 && NttCfg<LOGN>::T <= 256) ? 2 : 1)   // 8-byte residues: two workgroups per CU
 ntt_ct_multiply_kernel(char *__restrict__ c0, char *__restrict__ c1, char *__restrict__ c2,
                        const char *__restrict__ a0, const char *__restrict__ a1,
                        const char *__restrict__ b0, const char *__restrict__ b1,
