@@ -1104,10 +1104,11 @@ extern "C" int fhe_ct_relinearize(fhe_rns_ntt_t *h, const fhe_relin_keys_t *rk, 
 }
 
 // FHEContext::multiply as the reference declares it (src/fhe.cu:199-224: tensor product, then relinearize): (c0, c1) = relin(a (x) b).
-// Where the tensor-product and the key-switch kernel both exist in their one-launch forms, c2 never takes the 32-byte container
-// form: the tensor product writes it to a compact workspace (sizeof(residue) bytes per coefficient) and the key switch reads it from
-// there -- 2 launches, HBM traffic 4 S in + 2 S out + c2 at S/8 (S/4) per pass instead of 12 S.  Elsewhere: fhe_ct_multiply into a
-// container workspace followed by fhe_ct_relinearize.  Same bits either way (tests compare both with the oracle).
+// On the LDS-resident sizes of the word-sized classes the three components of the tensor product never take the 32-byte container
+// form: the tensor-product kernel(s) write c0, c1, c2 to a compact workspace (sizeof(residue) bytes per coefficient) and the
+// key-switch kernel reads its digit source (c2) and its addends (c0, c1) from there -- HBM traffic 4 S in + 2 S out + 3 compact
+// components written once and read back (c2 by every limb workgroup) instead of 12 S.  Elsewhere: fhe_ct_multiply into a container
+// workspace followed by fhe_ct_relinearize.  Same bits either way (tests compare both with the oracle).
 extern "C" int fhe_ct_multiply_relin(fhe_rns_ntt_t *h, const fhe_relin_keys_t *rk, void *d_c0, void *d_c1, const void *d_a0, const void *d_a1,
                                      const void *d_b0, const void *d_b1, uint32_t batch) {
     int rc = check_call(h, batch, "ct_multiply_relin"); if (rc) return rc;
@@ -1122,17 +1123,19 @@ extern "C" int fhe_ct_multiply_relin(fhe_rns_ntt_t *h, const fhe_relin_keys_t *r
                        fhe_dev::lds_compact_c2(eb, (int)h->log_n);
     const uint32_t polys = batch * h->L;
     if (fused) {
-        if ((rc = ensure_ws2(h, (size_t)polys * h->n * eb))) return rc;
+        const size_t cbytes = (size_t)polys * h->n * eb;         // one compact component
+        if ((rc = ensure_ws2(h, 3 * cbytes))) return rc;
+        char *c0c = (char *)h->d_ws2, *c1c = c0c + cbytes, *c2c = c1c + cbytes;
         fhe_dev::lds_launch_fn fn = fhe_dev::lds_lookup(lds_width_id(h), (int)h->log_n);
         if (!fn) return fail(FHE_ERR_UNSUPPORTED, "transform size outside the LDS-resident range");
-        fhe_dev::LdsArgs A{fhe_dev::LDS_CT_MULTIPLY, d_c0, d_c1, h->d_ws2, d_a0, d_a1, d_b0, d_b1, h->d_limbs, h->L, polys, h->stream};
+        fhe_dev::LdsArgs A{fhe_dev::LDS_CT_MULTIPLY, c0c, c1c, c2c, d_a0, d_a1, d_b0, d_b1, h->d_limbs, h->L, polys, h->stream};
         A.compact_c2 = true;
         fn(A);
-        if ((rc = post_launch(h->stream, "ntt_ct_multiply_kernel (compact c2)"))) return rc;
-        fhe_dev::LdsArgs B{fhe_dev::LDS_KEYSWITCH, d_c0, d_c1, nullptr, h->d_ws2, nullptr, nullptr, nullptr, h->d_limbs, h->L, polys, h->stream};
+        if ((rc = post_launch(h->stream, "tensor product (compact outputs)"))) return rc;
+        fhe_dev::LdsArgs B{fhe_dev::LDS_KEYSWITCH, d_c0, d_c1, nullptr, c2c, c0c, c1c, nullptr, h->d_limbs, h->L, polys, h->stream};
         B.kb = rk->d_pkb; B.ka = rk->d_pka; B.K = rk->K; B.w = rk->decomp_bits; B.compact_c2 = true;
         fn(B);
-        return post_launch(h->stream, "ntt_keyswitch kernel (compact c2)");
+        return post_launch(h->stream, "key switch (compact operands)");
     }
     if ((rc = ensure_ws2(h, (size_t)polys * h->n * 32))) return rc;
     if ((rc = do_ct_multiply(h, d_c0, d_c1, h->d_ws2, d_a0, d_a1, d_b0, d_b1, batch))) return rc;

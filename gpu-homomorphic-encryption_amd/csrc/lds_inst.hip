@@ -59,10 +59,9 @@ void CAT(lds_launch_, FHE_FIELD, FHE_LOGN)(const LdsArgs &A) {
         case LDS_CT_MULTIPLY:
             if constexpr (lds_ct_fused(sizeof(typename F::E), LOGN)) {
                 if (A.compact_c2) {
-                    if constexpr (lds_compact_c2(sizeof(typename F::E), LOGN))
-                        hipLaunchKernelGGL((ntt_ct_multiply_kernel<F, LOGN, false, true>), grid, block, 0, A.stream, (char *)A.r0, (char *)A.r1,
-                                           (char *)A.r2, (const char *)A.a0, (const char *)A.a1, (const char *)A.b0, (const char *)A.b1,
-                                           limbs, A.L);
+                    hipLaunchKernelGGL((ntt_ct_multiply_kernel<F, LOGN, false, true>), grid, block, 0, A.stream, (char *)A.r0, (char *)A.r1,
+                                       (char *)A.r2, (const char *)A.a0, (const char *)A.a1, (const char *)A.b0, (const char *)A.b1,
+                                       limbs, A.L);
                 } else if (A.square)
                     hipLaunchKernelGGL((ntt_ct_multiply_kernel<F, LOGN, true>), grid, block, 0, A.stream, (char *)A.r0, (char *)A.r1,
                                        (char *)A.r2, (const char *)A.a0, (const char *)A.a1, (const char *)A.b0, (const char *)A.b1,
@@ -71,6 +70,13 @@ void CAT(lds_launch_, FHE_FIELD, FHE_LOGN)(const LdsArgs &A) {
                     hipLaunchKernelGGL((ntt_ct_multiply_kernel<F, LOGN>), grid, block, 0, A.stream, (char *)A.r0, (char *)A.r1,
                                        (char *)A.r2, (const char *)A.a0, (const char *)A.a1, (const char *)A.b0, (const char *)A.b1,
                                        limbs, A.L);
+            } else if (A.compact_c2) {   // the same three launches with compact outputs
+                hipLaunchKernelGGL((ntt_multiply_kernel<F, LOGN, MULT_MINW, false, true>), grid, block, 0, A.stream, (char *)A.r0,
+                                   (const char *)A.a0, (const char *)A.b0, limbs, A.L, 0u);
+                hipLaunchKernelGGL((ntt_multiply_kernel<F, LOGN, MULT_MINW, false, true>), grid, block, 0, A.stream, (char *)A.r2,
+                                   (const char *)A.a1, (const char *)A.b1, limbs, A.L, 0u);
+                hipLaunchKernelGGL((ntt_mac2_kernel<F, LOGN, MULT_MINW, true>), grid, block, 0, A.stream, (char *)A.r1, (const char *)A.a0,
+                                   (const char *)A.b1, (const char *)A.a1, (const char *)A.b0, limbs, A.L);
             } else {   // four transformed operands exceed the register file: c0, c2 by the fused multiply, c1 by the two-product kernel
                 hipLaunchKernelGGL((ntt_multiply_kernel<F, LOGN, MULT_MINW>), grid, block, 0, A.stream, (char *)A.r0,
                                    (const char *)A.a0, (const char *)A.b0, limbs, A.L, 0u);
@@ -86,26 +92,26 @@ void CAT(lds_launch_, FHE_FIELD, FHE_LOGN)(const LdsArgs &A) {
                 if constexpr (lds_compact_c2(sizeof(E), LOGN)) {
                     if constexpr (lds_keyswitch_split(sizeof(E), LOGN))
                         hipLaunchKernelGGL((ntt_keyswitch_kernel<F, LOGN, 2, true, false, true>), dim3(A.polys * 2), block, 0, A.stream, (char *)A.r0, (char *)A.r1,
-                                           (const char *)A.a0, (const E *)A.kb, (const E *)A.ka, limbs, A.L, A.K, A.w);
+                                           (const char *)A.a0, (const char *)A.a1, (const char *)A.b0, (const E *)A.kb, (const E *)A.ka, limbs, A.L, A.K, A.w);
                     else
                         hipLaunchKernelGGL((ntt_keyswitch2_kernel<F, LOGN, 2, true>), grid, block, 0, A.stream, (char *)A.r0, (char *)A.r1,
-                                           (const char *)A.a0, (const E *)A.kb, (const E *)A.ka, limbs, A.L, A.K, A.w);
+                                           (const char *)A.a0, (const char *)A.a1, (const char *)A.b0, (const E *)A.kb, (const E *)A.ka, limbs, A.L, A.K, A.w);
                 }
             } else if constexpr (lds_keyswitch_split(sizeof(E), LOGN)) {
                 hipLaunchKernelGGL((ntt_keyswitch_kernel<F, LOGN, 2, true>), dim3(A.polys * 2), block, 0, A.stream, (char *)A.r0, (char *)A.r1,
-                                   (const char *)A.a0, (const E *)A.kb, (const E *)A.ka, limbs, A.L, A.K, A.w);
+                                   (const char *)A.a0, (const char *)A.r0, (const char *)A.r1, (const E *)A.kb, (const E *)A.ka, limbs, A.L, A.K, A.w);
             } else if (lds_paired_keyswitch(sizeof(E), LOGN) && !A.single_transforms) {
                 if constexpr (lds_paired_keyswitch(sizeof(E), LOGN))
                     hipLaunchKernelGGL((ntt_keyswitch2_kernel<F, LOGN, 2>), grid, block, 0, A.stream, (char *)A.r0, (char *)A.r1,
-                                       (const char *)A.a0, (const E *)A.kb, (const E *)A.ka, limbs, A.L, A.K, A.w);
+                                       (const char *)A.a0, (const char *)A.r0, (const char *)A.r1, (const E *)A.kb, (const E *)A.ka, limbs, A.L, A.K, A.w);
             } else {
                 if (lds_twiddles_in_lds(sizeof(E), LOGN) && !A.global_twiddles) {
                     if constexpr (lds_twiddles_in_lds(sizeof(E), LOGN))
                         hipLaunchKernelGGL((ntt_keyswitch_kernel<F, LOGN, 2, false, true>), grid, block, 0, A.stream, (char *)A.r0, (char *)A.r1,
-                                           (const char *)A.a0, (const E *)A.kb, (const E *)A.ka, limbs, A.L, A.K, A.w);
+                                           (const char *)A.a0, (const char *)A.r0, (const char *)A.r1, (const E *)A.kb, (const E *)A.ka, limbs, A.L, A.K, A.w);
                 } else {
                     hipLaunchKernelGGL((ntt_keyswitch_kernel<F, LOGN, 2, false>), grid, block, 0, A.stream, (char *)A.r0, (char *)A.r1,
-                                       (const char *)A.a0, (const E *)A.kb, (const E *)A.ka, limbs, A.L, A.K, A.w);
+                                       (const char *)A.a0, (const char *)A.r0, (const char *)A.r1, (const E *)A.kb, (const E *)A.ka, limbs, A.L, A.K, A.w);
                 }
             }
             break;

@@ -31,11 +31,9 @@ constexpr bool lds_twiddles_in_lds(int elem_bytes, int log_n) { return elem_byte
 constexpr bool lds_paired_keyswitch(int elem_bytes, int log_n) { return elem_bytes == 4 && log_n <= 14; }
 constexpr bool lds_paired_extprod(int elem_bytes, int log_n) { return elem_bytes == 4 && log_n <= 14; }
 
-// the fused FHEContext::multiply keeps c2 in compact form between the tensor-product and the key-switch kernel where both exist in
-// their default one-launch forms: fused tensor product, and the paired (4-byte residues) or split (8-byte residues) key-switch kernel
-constexpr bool lds_compact_c2(int elem_bytes, int log_n) {
-    return lds_ct_fused(elem_bytes, log_n) && (lds_keyswitch_split(elem_bytes, log_n) || lds_paired_keyswitch(elem_bytes, log_n));
-}
+// the fused FHEContext::multiply hands c0, c1, c2 from the tensor product to the key switch as compact polynomials wherever the
+// key-switch kernel exists in its default one-launch form: paired (4-byte residues up to 2^14) or split (8-byte residues, N = 2^15)
+constexpr bool lds_compact_c2(int elem_bytes, int log_n) { return lds_keyswitch_split(elem_bytes, log_n) || lds_paired_keyswitch(elem_bytes, log_n); }
 
 struct LdsArgs {
     int op;
@@ -54,7 +52,8 @@ struct LdsArgs {
     bool single_transforms = false;      // testing aid (FHE_HIP_NO_PAIRED_TRANSFORMS=1): one digit transform at a time
     uint32_t b_polys = 0;                // LDS_MULTIPLY: polynomials behind b0 (0 = as many as the batch; L = one RNS polynomial broadcast over the batch)
     bool square = false;                 // LDS_MULTIPLY: b0 == a0; LDS_CT_MULTIPLY: (b0, b1) == (a0, a1) -- the squaring forms of the kernels
-    bool compact_c2 = false;             // LDS_CT_MULTIPLY: r2 is the compact workspace; LDS_KEYSWITCH: a0 is (fused multiply + relinearise; see lds_compact_c2)
+    bool compact_c2 = false;             // fused multiply + relinearise (see lds_compact_c2): LDS_CT_MULTIPLY: r0, r1, r2 are compact workspace polynomials;
+                                         // LDS_KEYSWITCH: a0 (c2) and the addends a1 (c0), b0 (c1) are, r0 / r1 are the container outputs
     uint32_t top = 0;                    // LDS_PASS_* / LDS_SUB_*: number of stages above the 2^13 blocks (log2 n = 13 + top)
     bool rconst = false;                 // LDS_PASS_INV: scale with the constants that also absorb the 2^-W of a fused pointwise product
 };

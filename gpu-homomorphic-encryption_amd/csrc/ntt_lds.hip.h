@@ -686,7 +686,8 @@ ntt_inverse_kernel(char *__restrict__ data, const Limb<F> *__restrict__ limbs, u
 // SQUARE: b is a (the host passes the flag when the operand pointers are equal): one load, one forward transform, 2*S of traffic.
 // bcast != 0: b holds ONE RNS polynomial ([L][n]) that is multiplied into every element of the batch (served from L2 after its first
 // use: 2*S of HBM traffic per product).
-template <class F, int LOGN, int MINW = 1, bool SQUARE = false>
+// COMPACT_OUT: the result goes to a compact workspace polynomial (load_A_compact) -- pieces of the fused multiply + relinearise.
+template <class F, int LOGN, int MINW = 1, bool SQUARE = false, bool COMPACT_OUT = false>
 __global__ void __launch_bounds__(NttCfg<LOGN>::T, MINW)
 ntt_multiply_kernel(char *res, const char *a, const char *b,      // no __restrict__: res may alias a and / or b (in-place product)
                     const Limb<F> *__restrict__ limbs, uint32_t L, uint32_t bcast) {
@@ -717,9 +718,13 @@ ntt_multiply_kernel(char *res, const char *a, const char *b,      // no __restri
     inv_core<F, LOGN>(x, lds, tid, P, P.ninv_r, P.ninv_r_s, P.ninvw_r, P.ninvw_r_s);
 #pragma unroll
     for (int r = 0; r < 32; r++) x[r] = F::canon_inv(x[r], P.q);
-    lds_put<PatA<LOGN>>(lds, tid, x);
-    __syncthreads();
-    store_from_lds<F, LOGN>(res + off, lds, tid);
+    if constexpr (COMPACT_OUT) {
+        store_A_compact<F, LOGN>(reinterpret_cast<E *>(res) + (size_t)p * C::N, tid, x);
+    } else {
+        lds_put<PatA<LOGN>>(lds, tid, x);
+        __syncthreads();
+        store_from_lds<F, LOGN>(res + off, lds, tid);
+    }
 }
 
 // ---- transforms larger than the LDS range: N = 2^(LOGN + k), k = 1..3 --------------------------------------------------------------
@@ -819,7 +824,7 @@ word_pass_kernel(typename F::V16 *dst, const typename F::V16 *src, const Limb<F>
 // r = a0 (*) b1 + a1 (*) b0 in one launch (the c1 term of the tensor product) for configurations whose four
 // transformed operands do not fit the register file (8-byte residues at N = 2^14): at most three arrays are live.
 // HBM traffic = read 4 polynomials + write 1.
-template <class F, int LOGN, int MINW = 1>
+template <class F, int LOGN, int MINW = 1, bool COMPACT_OUT = false>
 __global__ void __launch_bounds__(NttCfg<LOGN>::T, MINW)
 ntt_mac2_kernel(char *__restrict__ res, const char *__restrict__ a0, const char *__restrict__ b1,
                 const char *__restrict__ a1, const char *__restrict__ b0, const Limb<F> *__restrict__ limbs, uint32_t L) {
@@ -852,16 +857,21 @@ ntt_mac2_kernel(char *__restrict__ res, const char *__restrict__ a0, const char 
     inv_core<F, LOGN>(acc, lds, tid, P, P.ninv_r, P.ninv_r_s, P.ninvw_r, P.ninvw_r_s);
 #pragma unroll
     for (int r = 0; r < 32; r++) acc[r] = F::canon_inv(acc[r], P.q);
-    lds_put<PatA<LOGN>>(lds, tid, acc);
-    __syncthreads();
-    store_from_lds<F, LOGN>(res + off, lds, tid);
+    if constexpr (COMPACT_OUT) {
+        store_A_compact<F, LOGN>(reinterpret_cast<E *>(res) + (size_t)p * C::N, tid, acc);
+    } else {
+        lds_put<PatA<LOGN>>(lds, tid, acc);
+        __syncthreads();
+        store_from_lds<F, LOGN>(res + off, lds, tid);
+    }
 }
 
 // FHEContext::multiply tensor product in one launch (src/fhe.cu:199-218): 4 forward + 3 inverse transforms,
 // HBM traffic = read 4 polynomials + write 3.
 // SQUARE: (b0, b1) is (a0, a1) (the host passes the flag when the operand pointers are equal -- squaring a ciphertext): two loads and
 // two forward transforms instead of four, c1 = 2 a0 a1; 5*S of traffic instead of 7*S.
-// COMPACT_C2: c2 goes to the compact workspace (see load_A_compact) instead of a container buffer: the fused multiply + relinearise.
+// COMPACT_C2: all three outputs go to compact workspace polynomials (see load_A_compact) instead of container buffers: the fused
+// multiply + relinearise, whose key-switch kernel reads them back as digit source (c2) and addends (c0, c1).
 template <class F, int LOGN, bool SQUARE = false, bool COMPACT_C2 = false>
 __global__ void __launch_bounds__(NttCfg<LOGN>::T, (sizeof(typename F::E) == 8 && NttCfg<LOGN>::T <= 256) ? 2 : 1)   // 8-byte residues: two workgroups per CU
 ntt_ct_multiply_kernel(char *__restrict__ c0, char *__restrict__ c1, char *__restrict__ c2,
@@ -910,16 +920,24 @@ ntt_ct_multiply_kernel(char *__restrict__ c0, char *__restrict__ c1, char *__res
     inv_core<F, LOGN>(A0, lds, tid, P, P.ninv_r, P.ninv_r_s, P.ninvw_r, P.ninvw_r_s);
 #pragma unroll
     for (int r = 0; r < 32; r++) A0[r] = F::canon_inv(A0[r], P.q);
-    lds_put<PatA<LOGN>>(lds, tid, A0);
-    __syncthreads();
-    store_from_lds<F, LOGN>(c0 + off, lds, tid);
+    if constexpr (COMPACT_C2) {
+        store_A_compact<F, LOGN>(reinterpret_cast<E *>(c0) + (size_t)p * C::N, tid, A0);
+    } else {
+        lds_put<PatA<LOGN>>(lds, tid, A0);
+        __syncthreads();
+        store_from_lds<F, LOGN>(c0 + off, lds, tid);
+    }
     __syncthreads();
     inv_core<F, LOGN>(A1, lds, tid, P, P.ninv_r, P.ninv_r_s, P.ninvw_r, P.ninvw_r_s);
 #pragma unroll
     for (int r = 0; r < 32; r++) A1[r] = F::canon_inv(A1[r], P.q);
-    lds_put<PatA<LOGN>>(lds, tid, A1);
-    __syncthreads();
-    store_from_lds<F, LOGN>(c1 + off, lds, tid);
+    if constexpr (COMPACT_C2) {
+        store_A_compact<F, LOGN>(reinterpret_cast<E *>(c1) + (size_t)p * C::N, tid, A1);
+    } else {
+        lds_put<PatA<LOGN>>(lds, tid, A1);
+        __syncthreads();
+        store_from_lds<F, LOGN>(c1 + off, lds, tid);
+    }
     __syncthreads();
     inv_core<F, LOGN>(B0, lds, tid, P, P.ninv_r, P.ninv_r_s, P.ninvw_r, P.ninvw_r_s);
 #pragma unroll
@@ -1005,7 +1023,7 @@ pack_keys_kernel(typename F::E *__restrict__ packed, const typename F::V16 *__re
 // (500+ cycles), which these register-starved kernels (2 waves per SIMD) cannot hide.  N * sizeof(TW) more LDS per workgroup.
 template <class F, int LOGN, int MINW = 1, bool SPLIT = false, bool TWL = false, bool COMPACT = false>
 __global__ void __launch_bounds__(NttCfg<LOGN>::T, MINW)
-ntt_keyswitch_kernel(char *__restrict__ c0, char *__restrict__ c1, const char *__restrict__ c2,
+ntt_keyswitch_kernel(char *c0, char *c1, const char *__restrict__ c2, const char *add0, const char *add1,   // add* = c* (in place) unless COMPACT
                      const typename F::E *__restrict__ kb, const typename F::E *__restrict__ ka,
                      const Limb<F> *__restrict__ limbs, uint32_t L, uint32_t K, uint32_t w) {
     using C = NttCfg<LOGN>;
@@ -1057,7 +1075,7 @@ ntt_keyswitch_kernel(char *__restrict__ c0, char *__restrict__ c1, const char *_
         // otherwise the barrier before the first exchange is inv_core's PRESYNC.
         if constexpr (TWL) { __syncthreads(); stage_twiddles<F, LOGN, false>(twl, P.itw, tid); __syncthreads(); }
         inv_core<F, LOGN, TWL, !TWL>(acc0, lds, tid, P, P.ninv, P.ninv_s, P.ninvw, P.ninvw_s, twl);
-        load_A<F, LOGN>(c0 + (size_t)p * (C::N * 32), tid, x);
+        load_src<F, LOGN, COMPACT>(add0, p, tid, x);
 #pragma unroll
         for (int r = 0; r < 32; r++) acc0[r] = F::ew_add(F::canon_inv(acc0[r], P.q), x[r], P.q);
         lds_put<PatA<LOGN>>(lds, tid, acc0);
@@ -1065,7 +1083,7 @@ ntt_keyswitch_kernel(char *__restrict__ c0, char *__restrict__ c1, const char *_
         store_from_lds<F, LOGN>(c0 + (size_t)p * (C::N * 32), lds, tid);
         __syncthreads();
         inv_core<F, LOGN, TWL>(acc1, lds, tid, P, P.ninv, P.ninv_s, P.ninvw, P.ninvw_s, twl);
-        load_A<F, LOGN>(c1 + (size_t)p * (C::N * 32), tid, x);
+        load_src<F, LOGN, COMPACT>(add1, p, tid, x);
 #pragma unroll
         for (int r = 0; r < 32; r++) acc1[r] = F::ew_add(F::canon_inv(acc1[r], P.q), x[r], P.q);
         lds_put<PatA<LOGN>>(lds, tid, acc1);
@@ -1099,7 +1117,7 @@ ntt_keyswitch_kernel(char *__restrict__ c0, char *__restrict__ c1, const char *_
         }
         F::regroup(acc, P.q, P.qinv);              // floating-point sums of L*K products: back below q before the inverse
         inv_core<F, LOGN, false, true>(acc, lds, tid, P, P.ninv, P.ninv_s, P.ninvw, P.ninvw_s);
-        load_A<F, LOGN>(dst + (size_t)p * (C::N * 32), tid, d);
+        load_src<F, LOGN, COMPACT>(half ? add1 : add0, p, tid, d);
 #pragma unroll
         for (int r = 0; r < 32; r++) acc[r] = F::ew_add(F::canon_inv(acc[r], P.q), d[r], P.q);
         lds_put<PatA<LOGN>>(lds, tid, acc);
@@ -1295,12 +1313,13 @@ __device__ __forceinline__ void mac_keys2(typename F::E (&acc0)[32], typename F:
 }
 
 // both accumulators back to the coefficient domain in lock step, + the addend polynomials, store  (tail of the paired kernels)
-template <class F, int LOGN>
+// add0 / add1: base pointers of the addend buffers (containers, or compact polynomials when COMPACT), p = polynomial index
+template <class F, int LOGN, bool COMPACT = false>
 __device__ __forceinline__ void finish_pair(typename F::E (&acc0)[32], typename F::E (&acc1)[32], typename F::E (&t0)[32], typename F::E (&t1)[32],
                                             typename F::E *lds0, typename F::E *lds1, uint32_t tid, const Limb<F> &P,
-                                            const char *add0, const char *add1, char *dst0, char *dst1) {
-    load_A<F, LOGN>(add0, tid, t0);            // issued first: the HBM latency hides under the inverse transforms
-    load_A<F, LOGN>(add1, tid, t1);
+                                            const char *add0, const char *add1, size_t p, char *dst0, char *dst1) {
+    load_src<F, LOGN, COMPACT>(add0, p, tid, t0);   // issued first: the HBM latency hides under the inverse transforms
+    load_src<F, LOGN, COMPACT>(add1, p, tid, t1);
     inv_core2<F, LOGN, true>(acc0, acc1, lds0, lds1, tid, P, P.ninv, P.ninv_s, P.ninvw, P.ninvw_s);
 #pragma unroll
     for (int r = 0; r < 32; r++) {
@@ -1316,7 +1335,7 @@ __device__ __forceinline__ void finish_pair(typename F::E (&acc0)[32], typename 
 
 template <class F, int LOGN, int MINW = 1, bool COMPACT = false>
 __global__ void __launch_bounds__(NttCfg<LOGN>::T, MINW)
-ntt_keyswitch2_kernel(char *__restrict__ c0, char *__restrict__ c1, const char *__restrict__ c2,
+ntt_keyswitch2_kernel(char *c0, char *c1, const char *__restrict__ c2, const char *add0, const char *add1,   // add* = c* (in place) unless COMPACT
                       const typename F::E *__restrict__ kb, const typename F::E *__restrict__ ka,
                       const Limb<F> *__restrict__ limbs, uint32_t L, uint32_t K, uint32_t w) {
     using C = NttCfg<LOGN>;
@@ -1358,8 +1377,8 @@ ntt_keyswitch2_kernel(char *__restrict__ c0, char *__restrict__ c1, const char *
         fwd_core<F, LOGN, false, true>(d0, lds, tid, P);
         mac_keys<F>(acc0, acc1, d0, kb, ka, ((size_t)jk * L + i) * C::N, tid, C::T, P);
     }
-    finish_pair<F, LOGN>(acc0, acc1, d0, d1, lds, lds + C::LDS_ELEMS, tid, P, c0 + (size_t)p * (C::N * 32), c1 + (size_t)p * (C::N * 32),
-                         c0 + (size_t)p * (C::N * 32), c1 + (size_t)p * (C::N * 32));
+    finish_pair<F, LOGN, COMPACT>(acc0, acc1, d0, d1, lds, lds + C::LDS_ELEMS, tid, P, add0, add1, p,
+                                  c0 + (size_t)p * (C::N * 32), c1 + (size_t)p * (C::N * 32));
 }
 
 template <class F, int LOGN, int MINW = 1>
@@ -1402,7 +1421,7 @@ ntt_extprod2_kernel(char *__restrict__ out0, char *__restrict__ out1, const char
         mac_keys2<F>(acc0, acc1, d0, d1, c0i ? kb1 : kb0, c0i ? ka1 : ka0, ((size_t)jk0 * L + i) * C::N, c1i ? kb1 : kb0, c1i ? ka1 : ka0,
                      ((size_t)jk1 * L + i) * C::N, tid, C::T, P);
     }
-    finish_pair<F, LOGN>(acc0, acc1, d0, d1, lds, lds + C::LDS_ELEMS, tid, P, in0 + (size_t)p * (C::N * 32), in1 + (size_t)p * (C::N * 32),
+    finish_pair<F, LOGN>(acc0, acc1, d0, d1, lds, lds + C::LDS_ELEMS, tid, P, in0, in1, p,
                          out0 + (size_t)p * (C::N * 32), out1 + (size_t)p * (C::N * 32));
 }
 
