@@ -250,7 +250,7 @@ struct fhe_rns_ntt {
     int wide_nl = 0;                    // FHE_WIDTH_256: 64-bit limbs per residue in those kernels (2: q < 2^127, 4: q < 2^255)
     bool wide_tiles = true;             // FHE_HIP_NO_WIDE_TILES=1: every stage as a global-memory pass (cross-check / A-B)
     bool no_square = false, single_transforms = false, global_twiddles = false, check_inputs = false, no_fused_keyswitch = false,
-         no_word_conversions = false, no_fused_blind_rotate = false, no_fused_ct_relin = false;   // environment switches, read once at creation
+         no_word_conversions = false, no_fused_blind_rotate = false, no_fused_ct_relin = false, no_compact_blind_rotate = false;   // environment switches, read once at creation
     std::vector<void *> d_tables;
     void *d_ws = nullptr; size_t ws_bytes = 0;
     void *d_ws2 = nullptr; size_t ws2_bytes = 0;   // c2 of the fused multiply + relinearise (compact or containers); separate from d_ws, which the general paths use
@@ -528,6 +528,7 @@ static int create_impl(fhe_rns_ntt **out, uint32_t n, const uint64_t (*moduli)[4
     h->no_word_conversions = getenv("FHE_HIP_NO_WORD_CONVERSIONS") != nullptr;
     h->no_fused_blind_rotate = getenv("FHE_HIP_NO_FUSED_BLIND_ROTATE") != nullptr;
     h->no_fused_ct_relin = getenv("FHE_HIP_NO_FUSED_CT_RELIN") != nullptr;
+    h->no_compact_blind_rotate = getenv("FHE_HIP_NO_COMPACT_BLIND_ROTATE") != nullptr;
     { const char *e = getenv("FHE_HIP_CHECK_INPUTS"); h->check_inputs = e && e[0] == '1'; }
     *out = h;
     return FHE_OK;
@@ -1417,11 +1418,12 @@ static int blind_rotate_step_general(fhe_rns_ntt_t *h, const fhe_relin_keys_t *r
 }
 // One step as ONE launch (word-sized classes with packed rows): (out0, out1) = (in0, in1) + ExtProd((X^a - 1) * in, RGSW).
 static int blind_rotate_step_fused(fhe_rns_ntt_t *h, const fhe_relin_keys_t *r0, const fhe_relin_keys_t *r1, void *out0, void *out1, const void *in0,
-                                   const void *in1, const uint32_t *d_shifts, uint32_t batch) {
+                                   const void *in1, const uint32_t *d_shifts, uint32_t batch, bool in_compact = false, bool out_compact = false) {
     fhe_dev::lds_launch_fn fn = fhe_dev::lds_lookup(lds_width_id(h), (int)h->log_n);
     if (!fn) return fail(FHE_ERR_UNSUPPORTED, "transform size outside the LDS-resident range");
     fhe_dev::LdsArgs A{fhe_dev::LDS_EXTPROD, out0, out1, nullptr, in0, in1, nullptr, nullptr, h->d_limbs, h->L, batch * h->L, h->stream};
     A.kb = r0->d_pkb; A.ka = r0->d_pka; A.kb1 = r1->d_pkb; A.ka1 = r1->d_pka; A.K = r0->K; A.w = r0->decomp_bits; A.shifts = d_shifts;
+    A.in_compact = in_compact; A.out_compact = out_compact;
     A.global_twiddles = h->global_twiddles;
     A.single_transforms = h->single_transforms;
     fn(A);
@@ -1451,6 +1453,23 @@ extern "C" int fhe_blind_rotate(fhe_rns_ntt_t *h, const fhe_relin_keys_t *const 
     if (!fused) {
         for (uint32_t s = 0; s < steps; s++)
             if ((rc = blind_rotate_step_general(h, rows_c0[s], rows_c1[s], d_acc0, d_acc1, d_shifts + (size_t)s * batch, d_tmp0, d_tmp1, batch))) return rc;
+        return FHE_OK;
+    }
+    // Paired kernel (4-byte residues up to N = 2^14), two or more steps: the accumulator pair lives in COMPACT form between the first and
+    // the last step (workspace ping-pong, 4 bytes per coefficient): the first step reads the caller's containers, the last one writes
+    // them, and every step in between moves S/8-sized polynomials -- the L limb workgroups of an accumulator each read all of it, which
+    // in container form is 3x the algorithmic traffic (profiles/r02_blindrotate_*).  The caller's scratch pair is not touched.
+    if (steps >= 2 && h->width == FHE_WIDTH_32 && !h->single_transforms && !h->no_compact_blind_rotate && fhe_dev::lds_paired_extprod(4, (int)h->log_n)) {
+        const size_t cbytes = (size_t)batch * h->L * h->n * 4;
+        if ((rc = ensure_ws2(h, 4 * cbytes))) return rc;
+        char *w0 = (char *)h->d_ws2;
+        char *pp[2][2] = {{w0, w0 + cbytes}, {w0 + 2 * cbytes, w0 + 3 * cbytes}};
+        for (uint32_t s = 0; s < steps; s++) {
+            const bool first = s == 0, last = s + 1 == steps;
+            const void *i0 = first ? d_acc0 : pp[(s + 1) & 1][0], *i1 = first ? d_acc1 : pp[(s + 1) & 1][1];
+            void *o0 = last ? d_acc0 : pp[s & 1][0], *o1 = last ? d_acc1 : pp[s & 1][1];
+            if ((rc = blind_rotate_step_fused(h, rows_c0[s], rows_c1[s], o0, o1, i0, i1, d_shifts + (size_t)s * batch, batch, !first, !last))) return rc;
+        }
         return FHE_OK;
     }
     // ping-pong between (acc0, acc1) and (tmp0, tmp1): one launch per step, 4*S bytes of HBM traffic per accumulator and step

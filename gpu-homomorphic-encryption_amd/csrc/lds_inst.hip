@@ -123,10 +123,16 @@ void CAT(lds_launch_, FHE_FIELD, FHE_LOGN)(const LdsArgs &A) {
                                    (const char *)A.a0, (const char *)A.a1, A.shifts, (const E *)A.kb, (const E *)A.ka, (const E *)A.kb1,
                                    (const E *)A.ka1, limbs, A.L, A.K, A.w);
             } else if (lds_paired_extprod(sizeof(E), LOGN) && !A.single_transforms) {
-                if constexpr (lds_paired_extprod(sizeof(E), LOGN))
-                    hipLaunchKernelGGL((ntt_extprod2_kernel<F, LOGN, 2>), grid, block, 0, A.stream, (char *)A.r0, (char *)A.r1,
-                                       (const char *)A.a0, (const char *)A.a1, A.shifts, (const E *)A.kb, (const E *)A.ka, (const E *)A.kb1,
-                                       (const E *)A.ka1, limbs, A.L, A.K, A.w);
+                if constexpr (lds_paired_extprod(sizeof(E), LOGN)) {
+#define EXTPROD2(IC, OC) hipLaunchKernelGGL((ntt_extprod2_kernel<F, LOGN, 2, IC, OC>), grid, block, 0, A.stream, (char *)A.r0, (char *)A.r1, \
+                                       (const char *)A.a0, (const char *)A.a1, A.shifts, (const E *)A.kb, (const E *)A.ka, (const E *)A.kb1, \
+                                       (const E *)A.ka1, limbs, A.L, A.K, A.w)
+                    if (A.in_compact && A.out_compact) EXTPROD2(true, true);
+                    else if (A.in_compact) EXTPROD2(true, false);
+                    else if (A.out_compact) EXTPROD2(false, true);
+                    else EXTPROD2(false, false);
+#undef EXTPROD2
+                }
             } else {
                 if (lds_twiddles_in_lds(sizeof(E), LOGN) && !A.global_twiddles) {
                     if constexpr (lds_twiddles_in_lds(sizeof(E), LOGN))

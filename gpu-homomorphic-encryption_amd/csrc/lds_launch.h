@@ -54,6 +54,7 @@ struct LdsArgs {
     bool square = false;                 // LDS_MULTIPLY: b0 == a0; LDS_CT_MULTIPLY: (b0, b1) == (a0, a1) -- the squaring forms of the kernels
     bool compact_c2 = false;             // fused multiply + relinearise (see lds_compact_c2): LDS_CT_MULTIPLY: r0, r1, r2 are compact workspace polynomials;
                                          // LDS_KEYSWITCH: a0 (c2) and the addends a1 (c0), b0 (c1) are, r0 / r1 are the container outputs
+    bool in_compact = false, out_compact = false;   // LDS_EXTPROD (paired kernel only): the accumulator pair a0, a1 / r0, r1 is in compact form
     uint32_t top = 0;                    // LDS_PASS_* / LDS_SUB_*: number of stages above the 2^13 blocks (log2 n = 13 + top)
     bool rconst = false;                 // LDS_PASS_INV: scale with the constants that also absorb the 2^-W of a fused pointwise product
 };

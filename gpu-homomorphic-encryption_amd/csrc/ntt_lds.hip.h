@@ -1135,12 +1135,12 @@ ntt_keyswitch_kernel(char *c0, char *c1, const char *__restrict__ c2, const char
 // 2*L*K forward + 2 inverse transforms per workgroup; HBM traffic per ciphertext: read in0, in1 (re-reads by the L workgroups of a
 // ciphertext are XCD-L2 / Infinity-Cache hits, same block map as the key-switch kernel) + write out0, out1 = 4 * S.
 // SPLIT as for the key-switch kernel: two workgroups per (b, i), one per output component.
-template <class F, int LOGN>
-__device__ __forceinline__ void load_monomial_A(const char *__restrict__ poly, typename F::E *lds, uint32_t tid, uint32_t a, typename F::E qj,
-                                                typename F::E (&x)[32]) {
+template <class F, int LOGN, bool COMPACT = false>
+__device__ __forceinline__ void load_monomial_A(const char *__restrict__ base, size_t poly_index, typename F::E *lds, uint32_t tid, uint32_t a,
+                                                typename F::E qj, typename F::E (&x)[32]) {
     using C = NttCfg<LOGN>;
     using E = typename F::E;
-    load_A<F, LOGN>(poly, tid, x);                  // p[i], i = tid + r*T
+    load_src<F, LOGN, COMPACT>(base, poly_index, tid, x);   // p[i], i = tid + r*T
     __syncthreads();                                // the previous transform's last reads of the exchange buffer are over
     lds_put<PatA<LOGN>>(lds, tid, x);
     __syncthreads();
@@ -1190,7 +1190,7 @@ ntt_extprod_kernel(char *__restrict__ out0, char *__restrict__ out1, const char 
             const char *src = c ? in1 : in0;
             const E *kb = c ? kb1 : kb0, *ka = c ? ka1 : ka0;
             for (uint32_t j = 0; j < L; j++) {
-                load_monomial_A<F, LOGN>(src + ((size_t)b * L + j) * (C::N * 32), lds, tid, a, limbs[j].q, x);
+                load_monomial_A<F, LOGN>(src, (size_t)b * L + j, lds, tid, a, limbs[j].q, x);
                 for (uint32_t k = 0; k < K; k++) {
 #pragma unroll
                     for (int r = 0; r < 32; r++) d[r] = F::digit(x[r], k * w, w);
@@ -1236,7 +1236,7 @@ ntt_extprod_kernel(char *__restrict__ out0, char *__restrict__ out1, const char 
             for (uint32_t j = 0; j < L; j++) {
                 const E qj = limbs[j].q;
                 for (uint32_t k = 0; k < K; k++) {
-                    load_monomial_A<F, LOGN>(src + ((size_t)b * L + j) * (C::N * 32), lds, tid, a, qj, d);
+                    load_monomial_A<F, LOGN>(src, (size_t)b * L + j, lds, tid, a, qj, d);
 #pragma unroll
                     for (int r = 0; r < 32; r++) d[r] = F::digit(d[r], k * w, w);
                     fwd_core<F, LOGN, false, true>(d, lds, tid, P);
@@ -1314,7 +1314,8 @@ __device__ __forceinline__ void mac_keys2(typename F::E (&acc0)[32], typename F:
 
 // both accumulators back to the coefficient domain in lock step, + the addend polynomials, store  (tail of the paired kernels)
 // add0 / add1: base pointers of the addend buffers (containers, or compact polynomials when COMPACT), p = polynomial index
-template <class F, int LOGN, bool COMPACT = false>
+// dst0 / dst1: base pointers of the output buffers (containers, or compact polynomials when COMPACT_OUT)
+template <class F, int LOGN, bool COMPACT = false, bool COMPACT_OUT = false>
 __device__ __forceinline__ void finish_pair(typename F::E (&acc0)[32], typename F::E (&acc1)[32], typename F::E (&t0)[32], typename F::E (&t1)[32],
                                             typename F::E *lds0, typename F::E *lds1, uint32_t tid, const Limb<F> &P,
                                             const char *add0, const char *add1, size_t p, char *dst0, char *dst1) {
@@ -1326,11 +1327,16 @@ __device__ __forceinline__ void finish_pair(typename F::E (&acc0)[32], typename 
         acc0[r] = F::ew_add(F::canon_inv(acc0[r], P.q), t0[r], P.q);
         acc1[r] = F::ew_add(F::canon_inv(acc1[r], P.q), t1[r], P.q);
     }
-    lds_put<PatA<LOGN>>(lds0, tid, acc0);
-    lds_put<PatA<LOGN>>(lds1, tid, acc1);
-    __syncthreads();
-    store_from_lds<F, LOGN>(dst0, lds0, tid);
-    store_from_lds<F, LOGN>(dst1, lds1, tid);
+    if constexpr (COMPACT_OUT) {
+        store_A_compact<F, LOGN>(reinterpret_cast<typename F::E *>(dst0) + p * NttCfg<LOGN>::N, tid, acc0);
+        store_A_compact<F, LOGN>(reinterpret_cast<typename F::E *>(dst1) + p * NttCfg<LOGN>::N, tid, acc1);
+    } else {
+        lds_put<PatA<LOGN>>(lds0, tid, acc0);
+        lds_put<PatA<LOGN>>(lds1, tid, acc1);
+        __syncthreads();
+        store_from_lds<F, LOGN>(dst0 + p * (NttCfg<LOGN>::N * 32), lds0, tid);
+        store_from_lds<F, LOGN>(dst1 + p * (NttCfg<LOGN>::N * 32), lds1, tid);
+    }
 }
 
 template <class F, int LOGN, int MINW = 1, bool COMPACT = false>
@@ -1377,11 +1383,13 @@ ntt_keyswitch2_kernel(char *c0, char *c1, const char *__restrict__ c2, const cha
         fwd_core<F, LOGN, false, true>(d0, lds, tid, P);
         mac_keys<F>(acc0, acc1, d0, kb, ka, ((size_t)jk * L + i) * C::N, tid, C::T, P);
     }
-    finish_pair<F, LOGN, COMPACT>(acc0, acc1, d0, d1, lds, lds + C::LDS_ELEMS, tid, P, add0, add1, p,
-                                  c0 + (size_t)p * (C::N * 32), c1 + (size_t)p * (C::N * 32));
+    finish_pair<F, LOGN, COMPACT>(acc0, acc1, d0, d1, lds, lds + C::LDS_ELEMS, tid, P, add0, add1, p, c0, c1);
 }
 
-template <class F, int LOGN, int MINW = 1>
+// IN_COMPACT / OUT_COMPACT: the accumulator pair is read from / written to compact polynomials (load_A_compact): inside fhe_blind_rotate
+// the accumulators stay in that form between the first and the last step of a loop, so a step moves 2 S/8 per limb workgroup in and
+// 2 S/8 out instead of 2 S each way (the L workgroups of an accumulator each read ALL its limbs).
+template <class F, int LOGN, int MINW = 1, bool IN_COMPACT = false, bool OUT_COMPACT = false>
 __global__ void __launch_bounds__(NttCfg<LOGN>::T, MINW)
 ntt_extprod2_kernel(char *__restrict__ out0, char *__restrict__ out1, const char *__restrict__ in0, const char *__restrict__ in1,
                     const uint32_t *__restrict__ shifts,
@@ -1398,7 +1406,7 @@ ntt_extprod2_kernel(char *__restrict__ out0, char *__restrict__ out1, const char
     const uint32_t p = b * L + i;
     const Limb<F> P = limbs[i];
     const uint32_t a = shifts[b] & (2 * C::N - 1);
-    const size_t ct = (size_t)b * L * (C::N * 32);
+    const size_t ct = (size_t)b * L;                     // first limb polynomial of this accumulator
     E acc0[32], acc1[32], d0[32], d1[32];
 #pragma unroll
     for (int r = 0; r < 32; r++) { acc0[r] = 0; acc1[r] = 0; }
@@ -1406,12 +1414,12 @@ ntt_extprod2_kernel(char *__restrict__ out0, char *__restrict__ out1, const char
     for (uint32_t g = 0; g < G; g += 2) {
         const uint32_t c0i = g / LK, jk0 = g % LK, j0 = jk0 / K, k0 = jk0 % K;
         const uint32_t c1i = (g + 1) / LK, jk1 = (g + 1) % LK, j1 = jk1 / K, k1 = jk1 % K;
-        load_monomial_A<F, LOGN>((c1i ? in1 : in0) + ct + (size_t)j1 * (C::N * 32), lds, tid, a, limbs[j1].q, d1);
+        load_monomial_A<F, LOGN, IN_COMPACT>(c1i ? in1 : in0, ct + j1, lds, tid, a, limbs[j1].q, d1);
         if (c0i == c1i && j0 == j1) {
 #pragma unroll
             for (int r = 0; r < 32; r++) d0[r] = F::digit(d1[r], k0 * w, w);
         } else {
-            load_monomial_A<F, LOGN>((c0i ? in1 : in0) + ct + (size_t)j0 * (C::N * 32), lds, tid, a, limbs[j0].q, d0);
+            load_monomial_A<F, LOGN, IN_COMPACT>(c0i ? in1 : in0, ct + j0, lds, tid, a, limbs[j0].q, d0);
 #pragma unroll
             for (int r = 0; r < 32; r++) d0[r] = F::digit(d0[r], k0 * w, w);
         }
@@ -1421,8 +1429,7 @@ ntt_extprod2_kernel(char *__restrict__ out0, char *__restrict__ out1, const char
         mac_keys2<F>(acc0, acc1, d0, d1, c0i ? kb1 : kb0, c0i ? ka1 : ka0, ((size_t)jk0 * L + i) * C::N, c1i ? kb1 : kb0, c1i ? ka1 : ka0,
                      ((size_t)jk1 * L + i) * C::N, tid, C::T, P);
     }
-    finish_pair<F, LOGN>(acc0, acc1, d0, d1, lds, lds + C::LDS_ELEMS, tid, P, in0, in1, p,
-                         out0 + (size_t)p * (C::N * 32), out1 + (size_t)p * (C::N * 32));
+    finish_pair<F, LOGN, IN_COMPACT, OUT_COMPACT>(acc0, acc1, d0, d1, lds, lds + C::LDS_ELEMS, tid, P, in0, in1, p, out0, out1);
 }
 
 // ---- relinearisation building blocks (general path; the fused key-switch kernels are above) --------------------

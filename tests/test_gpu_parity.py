@@ -738,7 +738,7 @@ def test_blind_rotate_step_matches_oracle(eng, oracle, n, spec, w, batch):
 @pytest.mark.parametrize("n,spec,w,batch,steps", [(8192, ("bits", 30, 4), 16, 9, 3), (2048, ("bits", 30, 2), 30, 17, 2), (16384, ("bits", 30, 3), 16, 2, 1),
                                                   (32768, ("bits", 30, 2), 16, 2, 2), (4096, ("bits", 40, 2), 20, 3, 3), (2048, ("bits", 60, 2), 32, 2, 2),
                                                   (256, ("bits", 250, 1), 64, 2, 2), (2048, ("bits", 64, 2), 32, 2, 3)])
-@pytest.mark.parametrize("fused", [True, False, "single"])
+@pytest.mark.parametrize("fused", [True, False, "single", "containers"])
 def test_blind_rotate_loop_matches_oracle(eng, oracle, monkeypatch, n, spec, w, batch, steps, fused):
     """fhe_blind_rotate: `steps` external products with a different RGSW row set and different shifts per step; the fused
     one-launch-per-step path (ping-pong buffers, odd and even step counts; digit transforms two at a time -- the default where
@@ -747,6 +747,8 @@ def test_blind_rotate_loop_matches_oracle(eng, oracle, monkeypatch, n, spec, w, 
         monkeypatch.setenv("FHE_HIP_NO_FUSED_BLIND_ROTATE", "1")
     elif fused == "single":
         monkeypatch.setenv("FHE_HIP_NO_PAIRED_TRANSFORMS", "1")
+    elif fused == "containers":     # fused steps, accumulators ping-pong through the caller's container buffers instead of the compact workspace
+        monkeypatch.setenv("FHE_HIP_NO_COMPACT_BLIND_ROTATE", "1")
     moduli = _moduli(spec, n); L = len(moduli)
     e = eng.RnsNttEngine(n, moduli); rp = oracle.RnsPlan(n, moduli)
     K = e.relin_num_digits(w)
