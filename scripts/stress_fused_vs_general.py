@@ -52,6 +52,23 @@ while time.time() - t0 < budget:
                 want = got
             elif not (np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])):
                 print(f"MISMATCH relin {tag} n={n} bits={bits} L={L} w={w} batch={batch} seed={seed} rep={rep}"); sys.exit(1)
+    # FHEContext::multiply as one call (compact c0 / c1 / c2 between the kernels) vs tensor product + relinearisation as two calls
+    ops = [rns_poly(seed + 7000 + i, moduli, n, batch) for i in range(4)]
+    want = None
+    for rep in range(2):
+        for tag in ("general", "fused", "fused-single"):
+            d = [pkg.DeviceBuffer.from_numpy(x) for x in ops]
+            o = [pkg.DeviceBuffer(ops[0].nbytes) for _ in range(3)]
+            if tag == "general":
+                engs[tag].ct_multiply(o[0], o[1], o[2], d[0], d[1], d[2], d[3], batch)
+                engs[tag].relinearize(keysets[tag][0], o[0], o[1], o[2], batch); launches += 2
+            else:
+                engs[tag].ct_multiply_relin(keysets[tag][0], o[0], o[1], d[0], d[1], d[2], d[3], batch); launches += 2
+            got = (o[0].download(shape), o[1].download(shape))
+            if want is None:
+                want = got
+            elif not (np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])):
+                print(f"MISMATCH ct_multiply_relin {tag} n={n} bits={bits} L={L} w={w} batch={batch} seed={seed} rep={rep}"); sys.exit(1)
     # blind rotation loop: fused ping-pong vs composition
     steps = int(rng.integers(1, 5))
     shifts = rng.integers(0, 2 * n, size=(steps, batch), dtype=np.uint32)
