@@ -919,6 +919,9 @@ def test_full_size_properties_config4_ciphertext_multiply(eng, oracle):
         assert np.array_equal(d.download(a0.shape), x)
     e.relinearize(rk, dC[0], dC[1], dC[2], batch)
     r0, r1 = dC[0].download(a0.shape), dC[1].download(a0.shape)
+    dE0, dE1 = eng.DeviceBuffer(a0.nbytes), eng.DeviceBuffer(a0.nbytes)
+    e.ct_multiply_relin(rk, dE0, dE1, dA0, dA1, dB0, dB1, batch)                      # the one-call form (compact workspace) == the two calls
+    assert np.array_equal(dE0.download(a0.shape), r0) and np.array_equal(dE1.download(a0.shape), r1)
     dZ = eng.DeviceBuffer(a0.nbytes); dZ.zero()
     e.relinearize(rk, dD[0], dD[1], dZ, batch)                                        # c2 = 0: nothing to switch
     assert np.array_equal(dD[0].download(a0.shape), c[0]) and np.array_equal(dD[1].download(a0.shape), c[1])
