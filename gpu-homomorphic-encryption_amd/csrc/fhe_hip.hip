@@ -1220,9 +1220,9 @@ static int to_rns_word(fhe_rns_ntt *h, void *d_rns, const void *d_values, uint32
         }
         int rc = upload(h, ops, &h->d_to_rns_w); if (rc) return rc;
     }
-    const size_t halves = (size_t)batch * h->L * h->n * 2;
-    hipLaunchKernelGGL((fhe_dev::to_rns_word_kernel<F, WT>), dim3(ew_grid(halves)), dim3(256), 0, h->stream, (V *)d_rns, (const V *)d_values,
-                       (const fhe_dev::Limb<F> *)h->d_limbs, (const E *)h->d_to_rns_w, h->L, h->log_n, halves);
+    const size_t containers = (size_t)batch * h->L * h->n;
+    hipLaunchKernelGGL((fhe_dev::to_rns_word_kernel<F, WT>), dim3(ew_grid(containers)), dim3(256), 0, h->stream, (V *)d_rns, (const V *)d_values,
+                       (const fhe_dev::Limb<F> *)h->d_limbs, (const E *)h->d_to_rns_w, h->L, h->log_n, containers);
     return post_launch(h->stream, "to_rns_word_kernel");
 }
 extern "C" int fhe_rns_to_rns(fhe_rns_ntt_t *h, void *d_rns, const void *d_values, uint32_t batch) {
@@ -1316,10 +1316,11 @@ static int base_convert_word(fhe_rns_ntt *h, fhe_rns_ntt *t, void *d_out, const 
         if ((rc = upload(h, minv, &h->d_bconv_w_minv)) || (rc = upload(h, mat, &h->d_bconv_w_mat))) return rc;   // earlier tables stay owned by d_tables
         h->bconv_w_target = t; h->bconv_w_moduli = t->moduli;
     }
-    const size_t halves = (size_t)batch * t->L * h->n * 2;
-    hipLaunchKernelGGL((fhe_dev::base_convert_word_kernel<F>), dim3(ew_grid(halves)), dim3(256), 0, h->stream, (V *)d_out, (const V *)d_in,
+    constexpr bool all_lanes = std::is_same<F, fhe_dev::F64>::value || std::is_same<F, fhe_dev::F64X>::value;
+    const size_t work = (size_t)batch * t->L * h->n * (all_lanes ? 1 : 2);
+    hipLaunchKernelGGL((fhe_dev::base_convert_word_kernel<F, all_lanes>), dim3(ew_grid(work)), dim3(256), 0, h->stream, (V *)d_out, (const V *)d_in,
                        (const fhe_dev::Limb<F> *)h->d_limbs, h->L, (const fhe_dev::Limb<F> *)t->d_limbs, t->L, (const E *)h->d_bconv_w_minv,
-                       (const E *)h->d_bconv_w_mat, h->log_n, halves);
+                       (const E *)h->d_bconv_w_mat, h->log_n, work);
     return post_launch(h->stream, "base_convert_word_kernel");
 }
 

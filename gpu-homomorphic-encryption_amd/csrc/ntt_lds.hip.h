@@ -1520,19 +1520,34 @@ rescale_word_kernel(typename F::V16 *__restrict__ out, const typename F::V16 *__
     }
 }
 
+// Every lane of a wave holds the residue `o` of one of 64 consecutive containers starting at half-container `dst`: lane pairs store
+// the value half and the zero half of each container (two instructions of 1 KiB consecutive bytes per wave), so the arithmetic that
+// produced `o` runs on all 64 lanes instead of on the even ones of a one-half-container-per-lane kernel.
+template <class F>
+__device__ __forceinline__ void store_wave_containers(typename F::V16 *dst, typename F::E o) {
+    using E = typename F::E;
+    const uint32_t lane = threadIdx.x & 63;
+    const E lo = __shfl(o, (int)(lane >> 1), 64), hi = __shfl(o, (int)(32 + (lane >> 1)), 64);
+    __builtin_nontemporal_store(F::pack((lane & 1) ? (E)0 : lo), dst + lane);
+    __builtin_nontemporal_store(F::pack((lane & 1) ? (E)0 : hi), dst + 64 + lane);
+}
+
 // out[b][j][x] = sum_i ([x_i * (Q/q_i)^-1]_{q_i} mod p_j) * ((Q/q_i) mod p_j) mod p_j   (RNSContext::base_extend, include/rns.cuh:47-48, declared only).
 // minv_ops[i] is an operand of source limb i, mat_ops[i * Lp + j] an operand of target limb j.  One half container of the output per lane.
-template <class F>
+// ALL_LANES: one output container per lane, stored by lane pairs (store_wave_containers): +8..10 % on the 64-bit integer fields, whose
+// constant products are the cost; the 4-byte and FP64 fields are bandwidth-bound either way and keep one half container per lane
+// (measured 5.0 vs 4.4 and 4.7 vs 4.5 TB/s).
+template <class F, bool ALL_LANES>
 __global__ void __launch_bounds__(256)
 base_convert_word_kernel(typename F::V16 *__restrict__ out, const typename F::V16 *__restrict__ in, const Limb<F> *__restrict__ src, uint32_t L,
                          const Limb<F> *__restrict__ dst, uint32_t Lp, const typename F::E *__restrict__ minv_ops,
-                         const typename F::E *__restrict__ mat_ops, uint32_t log_n, size_t out_halves) {
+                         const typename F::E *__restrict__ mat_ops, uint32_t log_n, size_t work /* containers if ALL_LANES, else half containers */) {
     using E = typename F::E;
     const size_t stride = (size_t)gridDim.x * blockDim.x, n = (size_t)1 << log_n;
-    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < out_halves; g += stride) {
+    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < work; g += stride) {   // n is a multiple of 256: whole waves
         E o = 0;
-        if (!(g & 1)) {
-            const size_t c = g >> 1, x = c & (n - 1), pl = c >> log_n, b = pl / Lp;
+        if (ALL_LANES || !(g & 1)) {
+            const size_t c = ALL_LANES ? g : g >> 1, x = c & (n - 1), pl = c >> log_n, b = pl / Lp;
             const uint32_t j = (uint32_t)(pl % Lp);
             const Limb<F> &D = dst[j];
             for (uint32_t i = 0; i < L; i++) {
@@ -1541,7 +1556,8 @@ base_convert_word_kernel(typename F::V16 *__restrict__ out, const typename F::V1
                 o = F::ew_add(o, mul_const<F>(mat_ops[(size_t)i * Lp + j], ti, D), D.q);   // t_i < q_i: a valid operand modulo p_j as it stands
             }
         }
-        __builtin_nontemporal_store(F::pack(o), out + g);
+        if constexpr (ALL_LANES) store_wave_containers<F>(out + 2 * (g - (threadIdx.x & 63)), o);
+        else __builtin_nontemporal_store(F::pack(o), out + g);
     }
 }
 
@@ -1552,27 +1568,25 @@ base_convert_word_kernel(typename F::V16 *__restrict__ out, const typename F::V1
 template <class F, class WT>     // WT: the word type the value is cut into (uint32_t for F32 and F52, uint64_t for F64)
 __global__ void __launch_bounds__(256)
 to_rns_word_kernel(typename F::V16 *__restrict__ rns, const typename F::V16 *__restrict__ values, const Limb<F> *__restrict__ limbs,
-                   const typename F::E *__restrict__ pow_ops, uint32_t L, uint32_t log_n, size_t out_halves) {
+                   const typename F::E *__restrict__ pow_ops, uint32_t L, uint32_t log_n, size_t out_containers) {
     using E = typename F::E;
     constexpr int NW = 32 / sizeof(WT), HW = NW / 2;                   // words per container / per 16-byte half
     typedef WT VecW __attribute__((ext_vector_type(HW)));
     const size_t stride = (size_t)gridDim.x * blockDim.x, n = (size_t)1 << log_n;
-    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < out_halves; g += stride) {
+    for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < out_containers; c += stride) {   // n is a multiple of 256: whole waves
+        const size_t x = c & (n - 1), pl = c >> log_n, b = pl / L;
+        const uint32_t l = (uint32_t)(pl % L);
+        const Limb<F> &P = limbs[l];
+        const VecW *v = reinterpret_cast<const VecW *>(values + ((b << log_n) + x) * 2);
+        const VecW lo = v[0], hi = v[1];
+        const E *ops = pow_ops + (size_t)l * NW;
         E o = 0;
-        if (!(g & 1)) {
-            const size_t c = g >> 1, x = c & (n - 1), pl = c >> log_n, b = pl / L;
-            const uint32_t l = (uint32_t)(pl % L);
-            const Limb<F> &P = limbs[l];
-            const VecW *v = reinterpret_cast<const VecW *>(values + ((b << log_n) + x) * 2);
-            const VecW lo = v[0], hi = v[1];
-            const E *ops = pow_ops + (size_t)l * NW;
 #pragma unroll
-            for (int k = 0; k < HW; k++) {
-                o = F::ew_add(o, mul_const<F>(ops[k], (E)lo[k], P), P.q);
-                o = F::ew_add(o, mul_const<F>(ops[HW + k], (E)hi[k], P), P.q);
-            }
+        for (int k = 0; k < HW; k++) {
+            o = F::ew_add(o, mul_const<F>(ops[k], (E)lo[k], P), P.q);
+            o = F::ew_add(o, mul_const<F>(ops[HW + k], (E)hi[k], P), P.q);
         }
-        __builtin_nontemporal_store(F::pack(o), rns + g);
+        store_wave_containers<F>(rns + 2 * (c - (threadIdx.x & 63)), o);
     }
 }
 
