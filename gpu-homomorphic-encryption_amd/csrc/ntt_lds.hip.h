@@ -486,6 +486,18 @@ __device__ __forceinline__ void load_src(const char *__restrict__ base, size_t p
     else load_A<F, LOGN>(base + poly_index * (NttCfg<LOGN>::N * 32), tid, x);
 }
 
+// Every lane of a wave holds the residue `o` of one of 64 consecutive containers starting at half-container `dst`: lane pairs store
+// the value half and the zero half of each container (two instructions of 1 KiB consecutive bytes per wave), so the arithmetic that
+// produced `o` runs on all 64 lanes instead of on the even ones of a one-half-container-per-lane kernel.
+template <class F>
+__device__ __forceinline__ void store_wave_containers(typename F::V16 *dst, typename F::E o) {
+    using E = typename F::E;
+    const uint32_t lane = threadIdx.x & 63;
+    const E lo = __shfl(o, (int)(lane >> 1), 64), hi = __shfl(o, (int)(32 + (lane >> 1)), 64);
+    __builtin_nontemporal_store(F::pack((lane & 1) ? (E)0 : lo), dst + lane);
+    __builtin_nontemporal_store(F::pack((lane & 1) ? (E)0 : hi), dst + 64 + lane);
+}
+
 // Store the whole polynomial from LDS as full containers: consecutive lanes write consecutive 16-byte
 // halves (even lane: {value, 0...}; odd lane: zeros), i.e. 1 KiB contiguous per wave instruction.
 template <class F, int LOGN>
@@ -782,7 +794,8 @@ ntt_sub_kernel(char *res, const char *a, const char *b, const Limb<F> *__restric
 // Lanes work in pairs: lanes 2c and 2c+1 both load the low word of container c (one request) and run the same butterflies; the even
 // lane then stores the value half of each output container and the odd lane the zero half, so a wave instruction writes 1 KiB of
 // consecutive bytes (like store_from_lds) instead of every other 16 bytes of 2 KiB: 5.5 instead of 4.1 TB/s on the pass, whose
-// arithmetic is far from binding (12 butterflies per 8 containers).  grid = (2^(log_n - R + 1) / 256, polys).
+// arithmetic is far from binding (12 butterflies per 8 containers; one column per lane with the outputs exchanged by shuffles was
+// measured for the 8-byte fields and is no faster).  grid = (2^(log_n - R + 1) / 256, polys).
 template <class F, int R, bool FWD>
 __global__ void __launch_bounds__(256)
 word_pass_kernel(typename F::V16 *dst, const typename F::V16 *src, const Limb<F> *__restrict__ limbs, uint32_t L, uint32_t log_n, uint32_t rconst) {
@@ -1518,18 +1531,6 @@ rescale_word_kernel(typename F::V16 *__restrict__ out, const typename F::V16 *__
             __builtin_nontemporal_store(F::pack((E)0), dst + 1);
         }
     }
-}
-
-// Every lane of a wave holds the residue `o` of one of 64 consecutive containers starting at half-container `dst`: lane pairs store
-// the value half and the zero half of each container (two instructions of 1 KiB consecutive bytes per wave), so the arithmetic that
-// produced `o` runs on all 64 lanes instead of on the even ones of a one-half-container-per-lane kernel.
-template <class F>
-__device__ __forceinline__ void store_wave_containers(typename F::V16 *dst, typename F::E o) {
-    using E = typename F::E;
-    const uint32_t lane = threadIdx.x & 63;
-    const E lo = __shfl(o, (int)(lane >> 1), 64), hi = __shfl(o, (int)(32 + (lane >> 1)), 64);
-    __builtin_nontemporal_store(F::pack((lane & 1) ? (E)0 : lo), dst + lane);
-    __builtin_nontemporal_store(F::pack((lane & 1) ? (E)0 : hi), dst + 64 + lane);
 }
 
 // out[b][j][x] = sum_i ([x_i * (Q/q_i)^-1]_{q_i} mod p_j) * ((Q/q_i) mod p_j) mod p_j   (RNSContext::base_extend, include/rns.cuh:47-48, declared only).
