@@ -66,6 +66,7 @@ def lib():
         "fhe_rns_ntt_destroy": ([vp], ci),
         "fhe_rns_ntt_set_stream": ([vp, vp], ci),
         "fhe_rns_ntt_width_class": ([vp], ci),
+        "fhe_rns_ntt_reserve": ([vp, u32], ci),
         "fhe_rns_ntt_forward": ([vp, vp, u32], ci),
         "fhe_rns_ntt_inverse": ([vp, vp, u32], ci),
         "fhe_rns_ntt_pointwise": ([vp, vp, vp, vp, u32], ci),
@@ -402,6 +403,10 @@ class RnsNttEngine:
 
     def relinearize(self, rk, d_c0, d_c1, d_c2, batch=1):
         _check(lib().fhe_ct_relinearize(self.h, rk.h, _ptr(d_c0), _ptr(d_c1), _ptr(d_c2), batch))
+
+    def reserve(self, batch):
+        """Pre-size the library workspaces for calls of up to `batch` units (needed before hipGraph capture)."""
+        _check(lib().fhe_rns_ntt_reserve(self.h, batch))
 
     def ct_multiply_relin(self, rk, d_c0, d_c1, d_a0, d_a1, d_b0, d_b1, batch=1):
         """FHEContext::multiply: tensor product + relinearisation in one call (two components out)."""

@@ -843,6 +843,17 @@ extern "C" int fhe_rns_ntt_set_stream(fhe_rns_ntt_t *h, void *stream) {
     h->stream = stream ? (hipStream_t)stream : h->own_stream;
     return FHE_OK;
 }
+// Pre-sizes the library-owned workspaces for calls of up to `batch` units, so that no later call allocates (hipMalloc synchronises
+// and cannot be captured into a hipGraph): the compact / container workspace of fhe_ct_multiply_relin and fhe_blind_rotate, and the
+// transform workspace of the general paths (full-width class, two-pass sizes).  Relinearisation on the general path sizes its digit
+// workspace by itself (bounded to 1 GiB, chunked).
+extern "C" int fhe_rns_ntt_reserve(fhe_rns_ntt_t *h, uint32_t batch) {
+    int rc = check_call(h, batch, "reserve"); if (rc) return rc;
+    const size_t S = (size_t)h->L * h->n * 32;
+    if ((rc = ensure_ws2(h, (size_t)batch * S))) return rc;            // >= 4 compact components of 8-byte residues, or one container component
+    if (h->width == FHE_WIDTH_256 || h->sub_top) rc = ensure_ws(h, 5 * (size_t)batch * S);
+    return rc;
+}
 extern "C" int fhe_rns_ntt_width_class(const fhe_rns_ntt_t *h) { return h ? h->width : fail(FHE_ERR_INVALID_ARG, "null handle"); }
 extern "C" int fhe_rns_ntt_forward(fhe_rns_ntt_t *h, void *d_data, uint32_t batch) {
     int rc = check_call(h, batch, "forward"); if (rc) return rc;
