@@ -408,6 +408,18 @@ def main():
                      # per 4-5 S of traffic and are limited by 32-bit integer multiply issue, not by HBM
                      "limiter": ("hbm" if args.op in ("multiply", "fwdinv", "ct") and eng.width_class in (1, 3) else "valu-int32-multiply")},
     }
+    # Two workloads keep the round-1 accounting (the container-level minimum of the step-by-step composition) so that rounds compare,
+    # although the calls they time now keep their intermediates compact inside the library; the smaller true minimum is reported too.
+    if args.op == "ctrelin" and not args.two_calls:
+        fused_min = 6 * S * B          # 4 S in (a0, a1, b0, b1) + 2 S out (c0, c1): c2 and the intermediate c0, c1 never leave the library
+        out["roofline"]["accounting"] = "12 S = tensor product 7 S + relinearisation 5 S (two-call minimum, as in round 1); fhe_ct_multiply_relin itself needs 6 S"
+        out["roofline"]["one_call_minimum_bytes"] = fused_min
+        out["roofline"]["frac_one_call_minimum"] = fused_min / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+    if args.op == "blindrotate":
+        loop_min = 4 * S * B           # the accumulator pair read once and written once per CALL; between steps it stays compact (S/8 per polynomial)
+        out["roofline"]["accounting"] = f"4 S per external product (a step in container form, as in round 1); a {args.br_steps}-step call itself needs 4 S in all"
+        out["roofline"]["one_call_minimum_bytes"] = loop_min
+        out["roofline"]["frac_one_call_minimum"] = loop_min / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
     tr = pmc_traffic(kernel.split("+")[0], args.op, n, L, args.bits, B)
     if tr:
         out["roofline"]["traffic"] = tr["bytes"]
