@@ -26,6 +26,9 @@ def init_process_group(backend=None):
     rank, world, local_rank = env_rank_world()
     if world == 1 and os.environ.get("FHE_BENCH_FORCE_DIST") != "1":
         return None
+    if world == 1:                              # FHE_BENCH_FORCE_DIST=1 without a launcher: a one-rank group on this host
+        for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29577")):
+            os.environ.setdefault(k, v)
     if backend is None:
         import torch
         backend = "nccl" if torch.cuda.is_available() else "gloo"
