@@ -57,6 +57,20 @@ def test_gpus_2_spawns_two_ranks_and_verifies_both_shards():
     assert "cpu_baseline" not in d and "gloo" in d["dist_backend"]
 
 
+@pytest.mark.gpu
+def test_one_rank_rccl_group_carries_the_barriers_and_gathers():
+    """FHE_BENCH_FORCE_DIST=1: the same RCCL calls the N > 1 run makes (init, barrier, all_reduce MAX, all_gather of the verification
+    words on device tensors) with a one-rank group on the one GPU of this box."""
+    env = dict(os.environ, FHE_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "64", "--no-cpu-baseline", "--no-extras"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert res.returncode == 0, res.stderr[-3000:]
+    d = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][0])
+    assert d["n_gpus"] == 1 and d["ranks_seen"] == 1 and d["verified"] is True and "nccl" in d["dist_backend"]
+
+
 def test_gpus_n_without_a_device_fails_loudly():
     """CPU container: the launcher starts N ranks, they find no HIP device, the parent exits non-zero (no silent 1-rank line)."""
     res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--steps", "1", "--warmup", "0",
