@@ -250,7 +250,7 @@ struct fhe_rns_ntt {
     int wide_nl = 0;                    // FHE_WIDTH_256: 64-bit limbs per residue in those kernels (2: q < 2^127, 4: q < 2^255)
     bool wide_tiles = true;             // FHE_HIP_NO_WIDE_TILES=1: every stage as a global-memory pass (cross-check / A-B)
     bool no_square = false, single_transforms = false, global_twiddles = false, check_inputs = false, no_fused_keyswitch = false,
-         no_word_conversions = false, no_fused_blind_rotate = false, no_fused_ct_relin = false, no_compact_blind_rotate = false;   // environment switches, read once at creation
+         no_word_conversions = false, no_fused_blind_rotate = false, no_fused_ct_relin = false, no_compact_blind_rotate = false, no_two_launch_ct = false;   // environment switches, read once at creation
     std::vector<void *> d_tables;
     void *d_ws = nullptr; size_t ws_bytes = 0;
     void *d_ws2 = nullptr; size_t ws2_bytes = 0;   // c2 of the fused multiply + relinearise (compact or containers); separate from d_ws, which the general paths use
@@ -529,6 +529,7 @@ static int create_impl(fhe_rns_ntt **out, uint32_t n, const uint64_t (*moduli)[4
     h->no_fused_blind_rotate = getenv("FHE_HIP_NO_FUSED_BLIND_ROTATE") != nullptr;
     h->no_fused_ct_relin = getenv("FHE_HIP_NO_FUSED_CT_RELIN") != nullptr;
     h->no_compact_blind_rotate = getenv("FHE_HIP_NO_COMPACT_BLIND_ROTATE") != nullptr;
+    h->no_two_launch_ct = getenv("FHE_HIP_NO_TWO_LAUNCH_CT") != nullptr;
     { const char *e = getenv("FHE_HIP_CHECK_INPUTS"); h->check_inputs = e && e[0] == '1'; }
     *out = h;
     return FHE_OK;
@@ -680,6 +681,15 @@ static int big_inverse(fhe_rns_ntt *h, void *data, uint32_t polys) {
     return lds_big(h, fhe_dev::LDS_PASS_INV, data, data, nullptr, polys, false, "word_pass_kernel");
 }
 
+// tensor product where the one-launch kernel does not exist (8-byte residues at N = 2^14, N = 2^15): workspace for the transformed
+// b-side of the two-launch form (ntt_forward_compact_kernel + ntt_ct_a_kernel)
+static int ct_workspace(fhe_rns_ntt *h, fhe_dev::LdsArgs &A) {
+    const int eb = h->width == FHE_WIDTH_32 ? 4 : 8;
+    if (h->no_two_launch_ct || fhe_dev::lds_ct_fused(eb, (int)h->log_n)) return FHE_OK;
+    int rc = ensure_ws(h, 2 * (size_t)A.polys * h->n * eb); if (rc) return rc;
+    A.ws = h->d_ws;
+    return FHE_OK;
+}
 static int lds_run(fhe_rns_ntt *h, int op, void *r0, void *r1, void *r2, const void *a0, const void *a1, const void *b0,
                    const void *b1, uint32_t polys, const char *what, uint32_t b_polys = 0) {
     fhe_dev::lds_launch_fn fn = fhe_dev::lds_lookup(lds_width_id(h), (int)h->log_n);
@@ -689,6 +699,7 @@ static int lds_run(fhe_rns_ntt *h, int op, void *r0, void *r1, void *r2, const v
     A.b_polys = b_polys;
     A.square = !b_polys && !h->no_square &&
                ((op == fhe_dev::LDS_MULTIPLY && a0 == b0) || (op == fhe_dev::LDS_CT_MULTIPLY && a0 == b0 && a1 == b1));
+    if (op == fhe_dev::LDS_CT_MULTIPLY) { int rc = ct_workspace(h, A); if (rc) return rc; }
     fn(A);
     return post_launch(h->stream, what);
 }
@@ -852,6 +863,7 @@ extern "C" int fhe_rns_ntt_reserve(fhe_rns_ntt_t *h, uint32_t batch) {
     const size_t S = (size_t)h->L * h->n * 32;
     if ((rc = ensure_ws2(h, (size_t)batch * S))) return rc;            // >= 4 compact components of 8-byte residues, or one container component
     if (h->width == FHE_WIDTH_256 || h->sub_top) rc = ensure_ws(h, 5 * (size_t)batch * S);
+    else rc = ensure_ws(h, (size_t)batch * S / 2);                     // transformed b-side of the two-launch tensor product (2 compact components)
     return rc;
 }
 extern "C" int fhe_rns_ntt_width_class(const fhe_rns_ntt_t *h) { return h ? h->width : fail(FHE_ERR_INVALID_ARG, "null handle"); }
@@ -1142,6 +1154,7 @@ extern "C" int fhe_ct_multiply_relin(fhe_rns_ntt_t *h, const fhe_relin_keys_t *r
         if (!fn) return fail(FHE_ERR_UNSUPPORTED, "transform size outside the LDS-resident range");
         fhe_dev::LdsArgs A{fhe_dev::LDS_CT_MULTIPLY, c0c, c1c, c2c, d_a0, d_a1, d_b0, d_b1, h->d_limbs, h->L, polys, h->stream};
         A.compact_c2 = true;
+        if ((rc = ct_workspace(h, A))) return rc;
         fn(A);
         if ((rc = post_launch(h->stream, "tensor product (compact outputs)"))) return rc;
         fhe_dev::LdsArgs B{fhe_dev::LDS_KEYSWITCH, d_c0, d_c1, nullptr, c2c, c0c, c1c, nullptr, h->d_limbs, h->L, polys, h->stream};

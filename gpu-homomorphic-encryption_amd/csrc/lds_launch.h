@@ -11,8 +11,9 @@ enum LdsOp { LDS_FORWARD = 0, LDS_INVERSE = 1, LDS_MULTIPLY = 2, LDS_CT_MULTIPLY
              // the top stages (r0 = dst, a0 = src) and the sub-transforms of the 2^top blocks (r0 = dst, a0 = src, b0 = second operand)
              LDS_PASS_FWD = 6, LDS_PASS_INV = 7, LDS_SUB_FORWARD = 8, LDS_SUB_INVERSE = 9, LDS_SUB_MULTIPLY = 10 };
 
-// true when the instance runs the tensor product as one fused launch; otherwise LDS_CT_MULTIPLY issues
-// multiply(c0), multiply(c2) and the two-product kernel for c1 (three launches, 11*S instead of 7*S bytes)
+// true when the instance runs the tensor product as one fused launch; otherwise LDS_CT_MULTIPLY issues two launches (LdsArgs::ws
+// set: NTT(b0), NTT(b1) into the compact workspace, then everything else; 7 transforms) or, without a workspace (testing aid
+// FHE_HIP_NO_TWO_LAUNCH_CT=1), multiply(c0), multiply(c2) and the two-product kernel for c1 (three launches, 11 transforms)
 constexpr bool lds_ct_fused(int elem_bytes, int log_n) { return elem_bytes == 4 ? log_n <= 14 : log_n <= 13; }   // 1024-thread blocks cap a thread at 128 VGPRs
 // key switching: 4-byte residues run one workgroup per (ciphertext, limb); 8-byte residues and 1024-thread blocks (N = 2^15)
 // two, one per key half (three live arrays instead of four)
@@ -55,6 +56,7 @@ struct LdsArgs {
     bool compact_c2 = false;             // fused multiply + relinearise (see lds_compact_c2): LDS_CT_MULTIPLY: r0, r1, r2 are compact workspace polynomials;
                                          // LDS_KEYSWITCH: a0 (c2) and the addends a1 (c0), b0 (c1) are, r0 / r1 are the container outputs
     bool in_compact = false, out_compact = false;   // LDS_EXTPROD (paired kernel only): the accumulator pair a0, a1 / r0, r1 is in compact form
+    void *ws = nullptr;                  // LDS_CT_MULTIPLY where !lds_ct_fused: 2 * polys * n residues of workspace for the transformed b-side
     uint32_t top = 0;                    // LDS_PASS_* / LDS_SUB_*: number of stages above the 2^13 blocks (log2 n = 13 + top)
     bool rconst = false;                 // LDS_PASS_INV: scale with the constants that also absorb the 2^-W of a fused pointwise product
 };

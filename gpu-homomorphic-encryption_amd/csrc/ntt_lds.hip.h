@@ -515,6 +515,25 @@ __device__ __forceinline__ void store_from_lds(char *__restrict__ poly, const ty
     }
 }
 
+// The same store for callers that hold a live register array across it: a ROLLED loop of eight containers per trip (the fully
+// scheduled form above keeps up to 64 addresses and values in flight and spills around a live array).
+template <class F, int LOGN>
+__device__ __forceinline__ void store_from_lds_rolled(char *__restrict__ poly, const typename F::E *lds, uint32_t tid) {
+    using C = NttCfg<LOGN>;
+    using E = typename F::E;
+    const uint32_t half = tid & 1, c0 = tid >> 1;
+    const E *p = lds + c0 + (c0 >> 5);
+    typename F::V16 *dst = reinterpret_cast<typename F::V16 *>(poly) + tid;
+#pragma unroll 1
+    for (int s0 = 0; s0 < 64; s0 += 8) {
+        E v[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) v[j] = p[(s0 + j) * (C::T / 2 + C::T / 64)];
+#pragma unroll
+        for (int j = 0; j < 8; j++) __builtin_nontemporal_store(F::pack(half ? (E)0 : v[j]), dst + (size_t)(s0 + j) * C::T);
+    }
+}
+
 // ---- whole-transform building blocks (data in registers, lds = workgroup scratch) ----------------------
 // natural-order coefficients in pattern A  ->  NTT values in pattern Z, in [0, 4q)
 // TWL: the non-uniform stages take their twiddles from `twl`, an LDS copy made by stage_twiddles<F, LOGN, true>.
@@ -877,6 +896,97 @@ ntt_mac2_kernel(char *__restrict__ res, const char *__restrict__ a0, const char 
         __syncthreads();
         store_from_lds<F, LOGN>(res + off, lds, tid);
     }
+}
+
+// ---- tensor product in TWO launches for configurations whose four transformed operands do not fit the register file (8-byte
+// residues at N = 2^14): 7 transforms instead of the 11 of multiply(c0) + multiply(c2) + mac2(c1).
+// Launch 1 (ntt_forward_compact_kernel, grid (polys, 2)): NTT(b0), NTT(b1) into compact workspace polynomials, in REGISTER order
+// (slot tid + r*T holds register r of thread tid after the last forward stage, still lazy) -- only ever multiplied pointwise against
+// registers of the same thread of launch 2, so no ordering is needed, and 8 instead of 32 bytes per coefficient.
+// Launch 2 (ntt_ct_a_kernel): NTT(a0); c0 = INTT(A0 . B0); t = A0 . B1; NTT(a1); c1 = INTT(t + A1 . B0); c2 = INTT(A1 . B1).  At most two
+// arrays are live across any transform, three in the pointwise phases.  HBM traffic: 2 S + 2 S/4 written, then 2 S + 4 S/4 read and
+// 3 S (or 3 S/4, compact outputs) written: 7.5 S (5.25 S) against 11 S (8.75 S).
+template <class F, int LOGN, int MINW = 1>
+__global__ void __launch_bounds__(NttCfg<LOGN>::T, MINW)
+ntt_forward_compact_kernel(typename F::E *__restrict__ w0, typename F::E *__restrict__ w1, const char *__restrict__ b0,
+                           const char *__restrict__ b1, const Limb<F> *__restrict__ limbs, uint32_t L) {
+    using C = NttCfg<LOGN>;
+    using E = typename F::E;
+    __shared__ E lds[C::LDS_ELEMS];
+    const uint32_t tid = threadIdx.x, p = blockIdx.x;
+    const Limb<F> P = limbs[p % L];
+    E x[32];
+    load_A<F, LOGN>((blockIdx.y ? b1 : b0) + (size_t)p * (C::N * 32), tid, x);
+    fwd_core<F, LOGN>(x, lds, tid, P);
+    store_A_compact<F, LOGN>((blockIdx.y ? w1 : w0) + (size_t)p * C::N, tid, x);
+}
+template <class F, int LOGN, bool COMPACT_OUT>
+__device__ __forceinline__ void ct_store(char *__restrict__ c, size_t p, typename F::E *lds, uint32_t tid, const typename F::E (&x)[32]) {
+    using C = NttCfg<LOGN>;
+    if constexpr (COMPACT_OUT) {
+        store_A_compact<F, LOGN>(reinterpret_cast<typename F::E *>(c) + p * C::N, tid, x);
+    } else {
+        lds_put<PatA<LOGN>>(lds, tid, x);      // the slots this thread read last
+        __syncthreads();
+        store_from_lds_rolled<F, LOGN>(c + p * (C::N * 32), lds, tid);
+    }
+}
+template <class F, int LOGN, int MINW = 1, bool COMPACT_OUT = false, bool EARLY = false>
+__global__ void __launch_bounds__(NttCfg<LOGN>::T, MINW)
+ntt_ct_a_kernel(char *__restrict__ c0, char *__restrict__ c1, char *__restrict__ c2, const char *__restrict__ a0, const char *__restrict__ a1,
+                const typename F::E *__restrict__ w0, const typename F::E *__restrict__ w1, const Limb<F> *__restrict__ limbs, uint32_t L) {
+    using C = NttCfg<LOGN>;
+    using E = typename F::E;
+    __shared__ E lds[C::LDS_ELEMS];
+    const uint32_t tid = threadIdx.x, p = blockIdx.x;
+    const Limb<F> P = limbs[p % L];
+    const size_t off = (size_t)p * (C::N * 32);
+    const E *B0 = w0 + (size_t)p * C::N, *B1 = w1 + (size_t)p * C::N;
+    E X[32], Y[32], T[32];
+    // CT_FENCE: the compiler may not move the next phase's 32 loads above the transform / store before it (they would be a third
+    // live array across it: the kernel spills 600+ bytes per lane without the fences)
+#define CT_FENCE() do { __builtin_amdgcn_sched_barrier(0); asm volatile("" ::: "memory"); } while (0)
+    load_A<F, LOGN>(a0 + off, tid, X);
+    fwd_core<F, LOGN>(X, lds, tid, P);
+    CT_FENCE();
+    load_A_compact<F, LOGN>(B0, tid, Y);
+#pragma unroll
+    for (int r = 0; r < 32; r++) { X[r] = F::canon_fwd(X[r], P.q, P.q2, P.qinv); T[r] = F::pw_mul(X[r], Y[r], P.q, P.qinv); }
+    if constexpr (EARLY) load_A_compact<F, LOGN>(B1, tid, Y);     // in flight under the inverse transform of c0 (a third live array)
+    else CT_FENCE();
+    inv_core<F, LOGN>(T, lds, tid, P, P.ninv_r, P.ninv_r_s, P.ninvw_r, P.ninvw_r_s);
+#pragma unroll
+    for (int r = 0; r < 32; r++) T[r] = F::canon_inv(T[r], P.q);
+    ct_store<F, LOGN, COMPACT_OUT>(c0, p, lds, tid, T);
+    CT_FENCE();
+    if constexpr (!EARLY) load_A_compact<F, LOGN>(B1, tid, Y);
+#pragma unroll
+    for (int r = 0; r < 32; r++) T[r] = F::pw_mul(X[r], Y[r], P.q, P.qinv);          // A0 . B1
+    CT_FENCE();
+    load_A<F, LOGN>(a1 + off, tid, X);
+    __syncthreads();
+    fwd_core<F, LOGN>(X, lds, tid, P);
+    CT_FENCE();
+    load_A_compact<F, LOGN>(B0, tid, Y);
+#pragma unroll
+    for (int r = 0; r < 32; r++) { X[r] = F::canon_fwd(X[r], P.q, P.q2, P.qinv); T[r] = F::pw_add(T[r], F::pw_mul(X[r], Y[r], P.q, P.qinv), P.q, P.q2); }
+    if constexpr (EARLY) load_A_compact<F, LOGN>(B1, tid, Y);
+    else CT_FENCE();
+    inv_core<F, LOGN>(T, lds, tid, P, P.ninv_r, P.ninv_r_s, P.ninvw_r, P.ninvw_r_s);
+#pragma unroll
+    for (int r = 0; r < 32; r++) T[r] = F::canon_inv(T[r], P.q);
+    ct_store<F, LOGN, COMPACT_OUT>(c1, p, lds, tid, T);
+    CT_FENCE();
+    if constexpr (!EARLY) load_A_compact<F, LOGN>(B1, tid, Y);
+#pragma unroll
+    for (int r = 0; r < 32; r++) T[r] = F::pw_mul(X[r], Y[r], P.q, P.qinv);          // A1 . B1
+    CT_FENCE();
+    __syncthreads();
+    inv_core<F, LOGN>(T, lds, tid, P, P.ninv_r, P.ninv_r_s, P.ninvw_r, P.ninvw_r_s);
+#pragma unroll
+    for (int r = 0; r < 32; r++) T[r] = F::canon_inv(T[r], P.q);
+    ct_store<F, LOGN, COMPACT_OUT>(c2, p, lds, tid, T);
+#undef CT_FENCE
 }
 
 // FHEContext::multiply tensor product in one launch (src/fhe.cu:199-218): 4 forward + 3 inverse transforms,

@@ -1158,6 +1158,35 @@ def test_squaring_forms_match_oracle(eng, oracle, monkeypatch, n, spec, batch, s
     assert np.array_equal(dA0.download(a0.shape), rp.polymul(a0, a0, threads=8))
 
 
+@pytest.mark.parametrize("n,spec,w,batch", [(16384, ("bits", 40, 2), 16, 2), (16384, ("bits", 60, 1), 32, 1), (16384, ("bits", 64, 1), 32, 2), (32768, ("bits", 30, 1), 16, 1)])
+@pytest.mark.parametrize("two_launch", [True, False])
+def test_tensor_product_without_the_one_launch_kernel(eng, oracle, monkeypatch, n, spec, w, batch, two_launch):
+    """Sizes whose four transformed operands do not fit the register file (8-byte residues at N = 2^14, N = 2^15): the tensor product runs
+    as NTT(b0), NTT(b1) into a compact workspace + one launch for the rest (7 transforms), or with FHE_HIP_NO_TWO_LAUNCH_CT=1 as
+    multiply + multiply + two-product kernel (11 transforms).  Both equal the oracle, alone and inside fhe_ct_multiply_relin."""
+    if not two_launch:
+        monkeypatch.setenv("FHE_HIP_NO_TWO_LAUNCH_CT", "1")
+    moduli = _moduli(spec, n); L = len(moduli)
+    e = eng.RnsNttEngine(n, moduli); rp = oracle.RnsPlan(n, moduli)
+    a0, a1, b0, b1 = (rns_poly(s, moduli, n, batch) for s in (71, 72, 73, 74))
+    d = [_up(eng, x) for x in (a0, a1, b0, b1)]
+    c = [eng.DeviceBuffer(a0.nbytes) for _ in range(3)]
+    for rep in range(2):                                         # the second call reuses the workspace
+        e.ct_multiply(c[0], c[1], c[2], d[0], d[1], d[2], d[3], batch)
+    t = rp.ct_multiply(a0, a1, b0, b1, threads=8)
+    for buf, want in zip(c, t):
+        assert np.array_equal(buf.download(a0.shape), want)
+    K = e.relin_num_digits(w)
+    kb = _random_keys(moduli, n, L * K, 1100); ka = _random_keys(moduli, n, L * K, 1900)
+    rk = e.import_relin_keys(w, [_up(eng, k) for k in kb], [_up(eng, k) for k in ka])
+    e.ct_multiply_relin(rk, c[0], c[1], d[0], d[1], d[2], d[3], batch)
+    w0, w1 = rp.relinearize(w, t[0], t[1], t[2], kb, ka, threads=8)
+    assert np.array_equal(c[0].download(a0.shape), w0)
+    assert np.array_equal(c[1].download(a0.shape), w1)
+    for buf, src in zip(d, (a0, a1, b0, b1)):
+        assert np.array_equal(buf.download(a0.shape), src)
+
+
 @pytest.mark.parametrize("n,spec,batch", [(8192, ("bits", 30, 4), 7), (4096, ("bits", 40, 2), 3), (2048, ("bits", 60, 2), 2), (256, ("bits", 250, 1), 3), (2048, ("bits", 64, 2), 2)])
 def test_multiply_by_one_shared_polynomial(eng, oracle, n, spec, batch):
     """fhe_rns_ntt_multiply_bcast: every element of a batch times ONE polynomial (a key, a plaintext); equals the element-wise products."""
