@@ -250,7 +250,7 @@ struct fhe_rns_ntt {
     int wide_nl = 0;                    // FHE_WIDTH_256: 64-bit limbs per residue in those kernels (2: q < 2^127, 4: q < 2^255)
     bool wide_tiles = true;             // FHE_HIP_NO_WIDE_TILES=1: every stage as a global-memory pass (cross-check / A-B)
     bool no_square = false, single_transforms = false, global_twiddles = false, check_inputs = false, no_fused_keyswitch = false,
-         no_word_conversions = false, no_fused_blind_rotate = false, no_fused_ct_relin = false, no_compact_blind_rotate = false, no_two_launch_ct = false;   // environment switches, read once at creation
+         no_word_conversions = false, no_fused_blind_rotate = false, no_fused_ct_relin = false, no_compact_blind_rotate = false, no_two_launch_ct = false, split_keyswitch = false;   // environment switches, read once at creation
     std::vector<void *> d_tables;
     void *d_ws = nullptr; size_t ws_bytes = 0;
     void *d_ws2 = nullptr; size_t ws2_bytes = 0;   // c2 of the fused multiply + relinearise (compact or containers); separate from d_ws, which the general paths use
@@ -530,6 +530,7 @@ static int create_impl(fhe_rns_ntt **out, uint32_t n, const uint64_t (*moduli)[4
     h->no_fused_ct_relin = getenv("FHE_HIP_NO_FUSED_CT_RELIN") != nullptr;
     h->no_compact_blind_rotate = getenv("FHE_HIP_NO_COMPACT_BLIND_ROTATE") != nullptr;
     h->no_two_launch_ct = getenv("FHE_HIP_NO_TWO_LAUNCH_CT") != nullptr;
+    h->split_keyswitch = getenv("FHE_HIP_SPLIT_KEYSWITCH") != nullptr;
     { const char *e = getenv("FHE_HIP_CHECK_INPUTS"); h->check_inputs = e && e[0] == '1'; }
     *out = h;
     return FHE_OK;
@@ -1100,7 +1101,8 @@ extern "C" int fhe_ct_relinearize(fhe_rns_ntt_t *h, const fhe_relin_keys_t *rk, 
         fhe_dev::LdsArgs A{fhe_dev::LDS_KEYSWITCH, d_c0, d_c1, nullptr, d_c2, nullptr, nullptr, nullptr, h->d_limbs, h->L, batch * h->L, h->stream};
         A.kb = rk->d_pkb; A.ka = rk->d_pka; A.K = rk->K; A.w = rk->decomp_bits;
         A.global_twiddles = h->global_twiddles;
-    A.single_transforms = h->single_transforms;
+        A.single_transforms = h->single_transforms;
+        A.joint3 = !h->split_keyswitch && fhe_dev::lds_keyswitch_joint3(h->width == FHE_WIDTH_32 ? 4 : 8, (int)h->log_n);
         fn(A);
         return post_launch(h->stream, "ntt_keyswitch_kernel");
     }
@@ -1159,6 +1161,7 @@ extern "C" int fhe_ct_multiply_relin(fhe_rns_ntt_t *h, const fhe_relin_keys_t *r
         if ((rc = post_launch(h->stream, "tensor product (compact outputs)"))) return rc;
         fhe_dev::LdsArgs B{fhe_dev::LDS_KEYSWITCH, d_c0, d_c1, nullptr, c2c, c0c, c1c, nullptr, h->d_limbs, h->L, polys, h->stream};
         B.kb = rk->d_pkb; B.ka = rk->d_pka; B.K = rk->K; B.w = rk->decomp_bits; B.compact_c2 = true;
+        B.joint3 = !h->split_keyswitch && fhe_dev::lds_keyswitch_joint3(eb, (int)h->log_n);
         fn(B);
         return post_launch(h->stream, "key switch (compact operands)");
     }

@@ -101,16 +101,27 @@ void CAT(lds_launch_, FHE_FIELD, FHE_LOGN)(const LdsArgs &A) {
             using E = typename F::E;
             if (A.compact_c2) {          // the host sets it only where lds_compact_c2 holds and the default kernels are selected
                 if constexpr (lds_compact_c2(sizeof(E), LOGN)) {
-                    if constexpr (lds_keyswitch_split(sizeof(E), LOGN))
+                    if constexpr (lds_keyswitch_split(sizeof(E), LOGN)) {
+                        if (A.joint3) {
+                            if constexpr (lds_keyswitch_joint3(sizeof(E), LOGN))
+                                hipLaunchKernelGGL((ntt_keyswitch3_kernel<F, LOGN, 2, true>), grid, block, 0, A.stream, (char *)A.r0, (char *)A.r1,
+                                                   (const char *)A.a0, (const char *)A.a1, (const char *)A.b0, (const E *)A.kb, (const E *)A.ka, limbs, A.L, A.K, A.w);
+                        } else
                         hipLaunchKernelGGL((ntt_keyswitch_kernel<F, LOGN, 2, true, false, true>), dim3(A.polys * 2), block, 0, A.stream, (char *)A.r0, (char *)A.r1,
                                            (const char *)A.a0, (const char *)A.a1, (const char *)A.b0, (const E *)A.kb, (const E *)A.ka, limbs, A.L, A.K, A.w);
+                    }
                     else
                         hipLaunchKernelGGL((ntt_keyswitch2_kernel<F, LOGN, 2, true>), grid, block, 0, A.stream, (char *)A.r0, (char *)A.r1,
                                            (const char *)A.a0, (const char *)A.a1, (const char *)A.b0, (const E *)A.kb, (const E *)A.ka, limbs, A.L, A.K, A.w);
                 }
             } else if constexpr (lds_keyswitch_split(sizeof(E), LOGN)) {
-                hipLaunchKernelGGL((ntt_keyswitch_kernel<F, LOGN, 2, true>), dim3(A.polys * 2), block, 0, A.stream, (char *)A.r0, (char *)A.r1,
-                                   (const char *)A.a0, (const char *)A.r0, (const char *)A.r1, (const E *)A.kb, (const E *)A.ka, limbs, A.L, A.K, A.w);
+                if (A.joint3) {
+                    if constexpr (lds_keyswitch_joint3(sizeof(E), LOGN))
+                        hipLaunchKernelGGL((ntt_keyswitch3_kernel<F, LOGN, 2, false>), grid, block, 0, A.stream, (char *)A.r0, (char *)A.r1,
+                                           (const char *)A.a0, (const char *)A.r0, (const char *)A.r1, (const E *)A.kb, (const E *)A.ka, limbs, A.L, A.K, A.w);
+                } else
+                    hipLaunchKernelGGL((ntt_keyswitch_kernel<F, LOGN, 2, true>), dim3(A.polys * 2), block, 0, A.stream, (char *)A.r0, (char *)A.r1,
+                                       (const char *)A.a0, (const char *)A.r0, (const char *)A.r1, (const E *)A.kb, (const E *)A.ka, limbs, A.L, A.K, A.w);
             } else if (lds_paired_keyswitch(sizeof(E), LOGN) && !A.single_transforms) {
                 if constexpr (lds_paired_keyswitch(sizeof(E), LOGN))
                     hipLaunchKernelGGL((ntt_keyswitch2_kernel<F, LOGN, 2>), grid, block, 0, A.stream, (char *)A.r0, (char *)A.r1,

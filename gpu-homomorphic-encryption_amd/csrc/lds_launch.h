@@ -18,6 +18,10 @@ constexpr bool lds_ct_fused(int elem_bytes, int log_n) { return elem_bytes == 4 
 // key switching: 4-byte residues run one workgroup per (ciphertext, limb); 8-byte residues and 1024-thread blocks (N = 2^15)
 // two, one per key half (three live arrays instead of four)
 constexpr bool lds_keyswitch_split(int elem_bytes, int log_n) { return elem_bytes == 8 || log_n >= 15; }
+// ... except 8-byte residues at N = 2^14 (one 512-thread workgroup per CU either way), where ONE workgroup per limb with both
+// accumulators and the digit polynomial live (ntt_keyswitch3_kernel: half the transforms, ~450 bytes per lane parked in scratch) beats
+// the split form by 5-8 % on one MI355X; LdsArgs::joint3 selects it (the host clears it under FHE_HIP_SPLIT_KEYSWITCH=1, a testing aid)
+constexpr bool lds_keyswitch_joint3(int elem_bytes, int log_n) { return elem_bytes == 8 && log_n == 14; }
 
 // key switching / external product in the one-workgroup-per-limb form: twiddle tables copied into LDS for 4-byte residues up
 // to N = 2^13 (exchange buffer + table = 65 KiB per workgroup, still two workgroups per CU).  Interleaved A/B on one MI355X
@@ -56,6 +60,7 @@ struct LdsArgs {
     bool compact_c2 = false;             // fused multiply + relinearise (see lds_compact_c2): LDS_CT_MULTIPLY: r0, r1, r2 are compact workspace polynomials;
                                          // LDS_KEYSWITCH: a0 (c2) and the addends a1 (c0), b0 (c1) are, r0 / r1 are the container outputs
     bool in_compact = false, out_compact = false;   // LDS_EXTPROD (paired kernel only): the accumulator pair a0, a1 / r0, r1 is in compact form
+    bool joint3 = false;                 // LDS_KEYSWITCH where lds_keyswitch_joint3 holds: one workgroup per limb with three live arrays (ntt_keyswitch3_kernel)
     void *ws = nullptr;                  // LDS_CT_MULTIPLY where !lds_ct_fused: 2 * polys * n residues of workspace for the transformed b-side
     uint32_t top = 0;                    // LDS_PASS_* / LDS_SUB_*: number of stages above the 2^13 blocks (log2 n = 13 + top)
     bool rconst = false;                 // LDS_PASS_INV: scale with the constants that also absorb the 2^-W of a fused pointwise product
