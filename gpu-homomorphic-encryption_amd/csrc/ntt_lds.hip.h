@@ -414,7 +414,7 @@ __device__ __forceinline__ void stage_twiddles(typename F::TW *twl, const typena
 // SUB: the 2^LOGN coefficients are block number (pre - 2^k) of a larger transform of 2^(LOGN + k) coefficients whose top k stages
 // ran elsewhere (word_pass_kernel); the stage on local bit b then uses the big table at (pre << (LOGN-1-b)) + (i >> (b+1)), which for
 // pre = 1 is the whole-transform formula.
-template <class F, int LOGN, class Pat, int KHI, int KLO, bool TWL = false, bool SUB = false, int FENCE = 0>   // FENCE: see fwd_core
+template <class F, int LOGN, class Pat, int KHI, int KLO, bool TWL = false, bool SUB = false>
 __device__ __forceinline__ void fwd_stages(typename F::E (&x)[32], uint32_t tid, const typename F::TW *__restrict__ tw, const Limb<F> &P, uint32_t pre = 1) {
     static_assert(!(TWL && Pat::TW_UNIFORM), "uniform stages read device memory");
     static_assert(!(TWL && SUB), "sub-transforms read their twiddles from device memory");
@@ -428,7 +428,6 @@ __device__ __forceinline__ void fwd_stages(typename F::E (&x)[32], uint32_t tid,
             if (r & (1 << k)) continue;
             const typename F::TW w = p[TWL ? tw_slot_off<Pat>(r, k) : (Pat::off(r) >> (b + 1))];
             F::fwd_bfly(x[r], x[r | (1 << k)], w, P);
-            if constexpr (FENCE > 0) { if (((((r >> (k + 1)) << k) | (r & ((1 << k) - 1))) % FENCE) == FENCE - 1) __builtin_amdgcn_sched_barrier(0); }   // every FENCE-th butterfly
         }
     }
 }
@@ -541,23 +540,21 @@ __device__ __forceinline__ void store_from_lds_rolled(char *__restrict__ poly, c
 // PRESYNC: the barrier that protects the exchange buffer from the PREVIOUS transform's last reads sits here, after the
 // register-only first group, instead of at the end of the caller's loop body: the latest legal place, where it coincides with
 // the transform's own first barrier (a wave that is ahead keeps computing instead of waiting early).
-// FENCE > 0: a scheduling fence after every FENCE-th butterfly of a stage -- bounds the twiddles and product temporaries in flight in
-// kernels that hold other arrays across the transform (costs some latency hiding; 0 = the compiler schedules a whole stage freely).
-template <class F, int LOGN, bool TWL = false, bool PRESYNC = false, bool SUB = false, int FENCE = 0>
+template <class F, int LOGN, bool TWL = false, bool PRESYNC = false, bool SUB = false>
 __device__ __forceinline__ void fwd_core(typename F::E (&x)[32], typename F::E *lds, uint32_t tid, const Limb<F> &P,
                                          const typename F::TW *twl = nullptr, uint32_t pre = 1) {
     using C = NttCfg<LOGN>;
     const typename F::TW *t2 = TWL ? twl : P.tw;
-    fwd_stages<F, LOGN, PatA<LOGN>, 4, 0, false, SUB, FENCE>(x, tid, P.tw, P, pre);
+    fwd_stages<F, LOGN, PatA<LOGN>, 4, 0, false, SUB>(x, tid, P.tw, P, pre);
     if constexpr (PRESYNC) __syncthreads();
     lds_put<PatA<LOGN>>(lds, tid, x);
     __syncthreads();
     lds_get<PatM<LOGN>>(lds, tid, x);
-    fwd_stages<F, LOGN, PatM<LOGN>, 4, 0, TWL, SUB, FENCE>(x, tid, t2, P, pre);
+    fwd_stages<F, LOGN, PatM<LOGN>, 4, 0, TWL, SUB>(x, tid, t2, P, pre);
     lds_put<PatM<LOGN>>(lds, tid, x);          // same slots this thread just read: no barrier needed before
     __syncthreads();
     lds_get<PatZ<LOGN>>(lds, tid, x);
-    fwd_stages<F, LOGN, PatZ<LOGN>, C::REM - 1, 0, TWL, SUB, FENCE>(x, tid, t2, P, pre);
+    fwd_stages<F, LOGN, PatZ<LOGN>, C::REM - 1, 0, TWL, SUB>(x, tid, t2, P, pre);
 }
 // ---- two forward transforms under ONE modulus at once ------------------------------------------------------------------
 // The key-switch and external-product kernels transform many digit polynomials under the same modulus.  Doing two of them
@@ -1256,9 +1253,6 @@ ntt_keyswitch_kernel(char *c0, char *c1, const char *__restrict__ c2, const char
 // polynomial; the c2 limb is re-read for every digit (compact workspace: N * 8 bytes from L2) instead of being held.  Against the SPLIT
 // form of ntt_keyswitch_kernel (two workgroups per limb, one per key half, every digit transform computed twice) this halves the
 // transforms; the register file is exceeded by what the compiler parks in scratch around the transforms.
-#ifndef KS3_FENCE
-#define KS3_FENCE 0
-#endif
 template <class F, int LOGN, int MINW = 1, bool COMPACT = false>
 __global__ void __launch_bounds__(NttCfg<LOGN>::T, MINW)
 ntt_keyswitch3_kernel(char *c0, char *c1, const char *__restrict__ c2, const char *add0, const char *add1,
@@ -1283,7 +1277,7 @@ ntt_keyswitch3_kernel(char *c0, char *c1, const char *__restrict__ c2, const cha
             load_src<F, LOGN, COMPACT>(c2, (size_t)b * L + j, tid, d);
 #pragma unroll
             for (int r = 0; r < 32; r++) d[r] = F::digit(d[r], k * w, w);
-            fwd_core<F, LOGN, false, true, false, KS3_FENCE>(d, lds, tid, P);
+            fwd_core<F, LOGN, false, true>(d, lds, tid, P);
             __builtin_amdgcn_sched_barrier(0);   // keep the key loads out of the transform
             const size_t tbl = ((size_t)(j * K + k) * L + i) * C::N;
             const VecE *pb = reinterpret_cast<const VecE *>(kb + tbl) + tid, *pa = reinterpret_cast<const VecE *>(ka + tbl) + tid;
