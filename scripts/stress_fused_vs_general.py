@@ -18,7 +18,7 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 t0 = time.time(); cases = 0; launches = 0
 while time.time() - t0 < budget:
-    log_n = int(rng.integers(11, 16)); n = 1 << log_n
+    log_n = int(rng.choice([11, 12, 13, 14, 14, 14, 15])); n = 1 << log_n
     bits = int(rng.choice([30, 30, 30, 40, 60, 64])) if log_n <= 14 else 30
     L = int(rng.integers(1, 7 if bits == 30 else 4))
     w = int(rng.choice([8, 16, 20, 30])) if bits == 30 else int(rng.choice([16, 20, 32]))
@@ -34,7 +34,8 @@ while time.time() - t0 < budget:
             for k in env:
                 os.environ.pop(k, None)
     engs = {"fused": make(), "general": make(FHE_HIP_NO_FUSED_KEYSWITCH="1", FHE_HIP_NO_FUSED_BLIND_ROTATE="1"),
-            "fused-single": make(FHE_HIP_NO_PAIRED_TRANSFORMS="1")}
+            "fused-single": make(FHE_HIP_NO_PAIRED_TRANSFORMS="1"),
+            "fused-alt": make(FHE_HIP_NO_TWO_LAUNCH_CT="1", FHE_HIP_SPLIT_KEYSWITCH="1")}   # the other forms of the N = 2^14 / 2^15 kernels
     K = engs["fused"].relin_num_digits(w)
     seed = int(rng.integers(1 << 30))
     keys = [[pkg.DeviceBuffer.from_numpy(rns_poly(seed + 31 * i + 997 * h, moduli, n, 1)) for i in range(L * K)] for h in range(4)]
@@ -44,7 +45,7 @@ while time.time() - t0 < budget:
     # relinearisation, repeated: every repetition must give the same bits
     want = None
     for rep in range(4):
-        for tag in ("general", "fused", "fused-single"):
+        for tag in ("general", "fused", "fused-single", "fused-alt"):
             d = [pkg.DeviceBuffer.from_numpy(x) for x in c]
             engs[tag].relinearize(keysets[tag][0], d[0], d[1], d[2], batch); launches += 1
             got = (d[0].download(shape), d[1].download(shape))
@@ -56,7 +57,7 @@ while time.time() - t0 < budget:
     ops = [rns_poly(seed + 7000 + i, moduli, n, batch) for i in range(4)]
     want = None
     for rep in range(2):
-        for tag in ("general", "fused", "fused-single"):
+        for tag in ("general", "fused", "fused-single", "fused-alt"):
             d = [pkg.DeviceBuffer.from_numpy(x) for x in ops]
             o = [pkg.DeviceBuffer(ops[0].nbytes) for _ in range(3)]
             if tag == "general":
@@ -75,7 +76,7 @@ while time.time() - t0 < budget:
     dSh = pkg.DeviceBuffer.from_numpy(shifts)
     want = None
     for rep in range(3):
-        for tag in ("general", "fused", "fused-single"):
+        for tag in ("general", "fused", "fused-single", "fused-alt"):
             a0, a1 = pkg.DeviceBuffer.from_numpy(c[0]), pkg.DeviceBuffer.from_numpy(c[1])
             t0b, t1b = pkg.DeviceBuffer(c[0].nbytes), pkg.DeviceBuffer(c[0].nbytes)
             engs[tag].blind_rotate([keysets[tag][0]] * steps, [keysets[tag][1]] * steps, a0, a1, dSh, t0b, t1b, batch); launches += steps
