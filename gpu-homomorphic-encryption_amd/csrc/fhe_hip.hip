@@ -1452,6 +1452,7 @@ static int blind_rotate_step_fused(fhe_rns_ntt_t *h, const fhe_relin_keys_t *r0,
     fhe_dev::LdsArgs A{fhe_dev::LDS_EXTPROD, out0, out1, nullptr, in0, in1, nullptr, nullptr, h->d_limbs, h->L, batch * h->L, h->stream};
     A.kb = r0->d_pkb; A.ka = r0->d_pka; A.kb1 = r1->d_pkb; A.ka1 = r1->d_pka; A.K = r0->K; A.w = r0->decomp_bits; A.shifts = d_shifts;
     A.in_compact = in_compact; A.out_compact = out_compact;
+    A.joint3 = !h->split_keyswitch && fhe_dev::lds_keyswitch_joint3(h->width == FHE_WIDTH_32 ? 4 : 8, (int)h->log_n);
     A.global_twiddles = h->global_twiddles;
     A.single_transforms = h->single_transforms;
     fn(A);

@@ -141,6 +141,12 @@ void CAT(lds_launch_, FHE_FIELD, FHE_LOGN)(const LdsArgs &A) {
         case LDS_EXTPROD: {
             using E = typename F::E;
             if constexpr (lds_keyswitch_split(sizeof(E), LOGN)) {
+                if (A.joint3) {
+                    if constexpr (lds_keyswitch_joint3(sizeof(E), LOGN))
+                        hipLaunchKernelGGL((ntt_extprod3_kernel<F, LOGN, 2>), grid, block, 0, A.stream, (char *)A.r0, (char *)A.r1,
+                                           (const char *)A.a0, (const char *)A.a1, A.shifts, (const E *)A.kb, (const E *)A.ka, (const E *)A.kb1,
+                                           (const E *)A.ka1, limbs, A.L, A.K, A.w);
+                } else
                 hipLaunchKernelGGL((ntt_extprod_kernel<F, LOGN, 2, true>), dim3(A.polys * 2), block, 0, A.stream, (char *)A.r0, (char *)A.r1,
                                    (const char *)A.a0, (const char *)A.a1, A.shifts, (const E *)A.kb, (const E *)A.ka, (const E *)A.kb1,
                                    (const E *)A.ka1, limbs, A.L, A.K, A.w);

@@ -1454,6 +1454,79 @@ ntt_extprod_kernel(char *__restrict__ out0, char *__restrict__ out1, const char 
     }
 }
 
+// External product for the 8-byte residues at N = 2^14 in ONE workgroup per (accumulator, limb) with three live arrays (both output
+// accumulators and the digit polynomial; the input limb is re-read, rotated, for every digit) -- the counterpart of
+// ntt_keyswitch3_kernel: half the transforms of the SPLIT form above.
+template <class F, int LOGN, int MINW = 1>
+__global__ void __launch_bounds__(NttCfg<LOGN>::T, MINW)
+ntt_extprod3_kernel(char *__restrict__ out0, char *__restrict__ out1, const char *__restrict__ in0, const char *__restrict__ in1,
+                    const uint32_t *__restrict__ shifts,
+                    const typename F::E *__restrict__ kb0, const typename F::E *__restrict__ ka0,
+                    const typename F::E *__restrict__ kb1, const typename F::E *__restrict__ ka1,
+                    const Limb<F> *__restrict__ limbs, uint32_t L, uint32_t K, uint32_t w) {
+    using C = NttCfg<LOGN>;
+    using E = typename F::E;
+    constexpr int VPL = 16 / sizeof(E), NCH = 32 / VPL;
+    typedef E VecE __attribute__((ext_vector_type(VPL)));
+    __shared__ E lds[C::LDS_ELEMS];
+    const uint32_t tid = threadIdx.x, bid = blockIdx.x, full = (gridDim.x / (8 * L)) * (8 * L);
+    uint32_t b, i;
+    if (bid < full) { const uint32_t s = bid >> 3; b = (bid & 7) + 8 * (s / L); i = s % L; }
+    else { b = bid / L; i = bid % L; }
+    const uint32_t p = b * L + i;
+    const Limb<F> P = limbs[i];
+    const uint32_t a = shifts[b] & (2 * C::N - 1);
+    E acc0[32], acc1[32], d[32];
+#pragma unroll
+    for (int r = 0; r < 32; r++) { acc0[r] = 0; acc1[r] = 0; }
+    for (uint32_t c = 0; c < 2; c++) {
+        const char *src = c ? in1 : in0;
+        const E *kb = c ? kb1 : kb0, *ka = c ? ka1 : ka0;
+        for (uint32_t j = 0; j < L; j++) {
+            const E qj = limbs[j].q;
+            for (uint32_t k = 0; k < K; k++) {
+                load_monomial_A<F, LOGN>(src, (size_t)b * L + j, lds, tid, a, qj, d);
+#pragma unroll
+                for (int r = 0; r < 32; r++) d[r] = F::digit(d[r], k * w, w);
+                fwd_core<F, LOGN, false, true>(d, lds, tid, P);
+                __builtin_amdgcn_sched_barrier(0);   // keep the key loads out of the transform
+                const size_t tbl = ((size_t)(j * K + k) * L + i) * C::N;
+                const VecE *pb = reinterpret_cast<const VecE *>(kb + tbl) + tid, *pa = reinterpret_cast<const VecE *>(ka + tbl) + tid;
+#pragma unroll
+                for (int ch = 0; ch < NCH; ch++) {
+                    const VecE vb = pb[ch * C::T], va = pa[ch * C::T];
+#pragma unroll
+                    for (int e = 0; e < VPL; e++) {
+                        const int r = ch * VPL + e;
+                        acc0[r] = F::pw_add(acc0[r], F::pw_mul(vb[e], d[r], P.q, P.qinv), P.q, P.q2);
+                        acc1[r] = F::pw_add(acc1[r], F::pw_mul(va[e], d[r], P.q, P.qinv), P.q, P.q2);
+                    }
+                    if ((ch & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        F::regroup(acc0, P.q, P.qinv);             // floating-point sums of L*K products: back below q (no-op for the integer fields)
+        F::regroup(acc1, P.q, P.qinv);
+    }
+    inv_core<F, LOGN, false, true>(acc0, lds, tid, P, P.ninv, P.ninv_s, P.ninvw, P.ninvw_s);
+    __builtin_amdgcn_sched_barrier(0);
+    load_A<F, LOGN>(in0 + (size_t)p * (C::N * 32), tid, d);
+#pragma unroll
+    for (int r = 0; r < 32; r++) acc0[r] = F::ew_add(F::canon_inv(acc0[r], P.q), d[r], P.q);
+    lds_put<PatA<LOGN>>(lds, tid, acc0);
+    __syncthreads();
+    store_from_lds_rolled<F, LOGN>(out0 + (size_t)p * (C::N * 32), lds, tid);
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+    inv_core<F, LOGN>(acc1, lds, tid, P, P.ninv, P.ninv_s, P.ninvw, P.ninvw_s);
+    load_A<F, LOGN>(in1 + (size_t)p * (C::N * 32), tid, d);
+#pragma unroll
+    for (int r = 0; r < 32; r++) acc1[r] = F::ew_add(F::canon_inv(acc1[r], P.q), d[r], P.q);
+    lds_put<PatA<LOGN>>(lds, tid, acc1);
+    __syncthreads();
+    store_from_lds<F, LOGN>(out1 + (size_t)p * (C::N * 32), lds, tid);
+}
+
 // ---- paired forms of the key-switch and external-product kernels (4-byte residues) --------------------------------------
 // Same results as ntt_keyswitch_kernel / ntt_extprod_kernel (SPLIT = false); the digit polynomials are transformed two at a
 // time (fwd_core2).  Registers: acc0, acc1, d0, d1 (the undecomposed limb is not kept: both digits of a pair are cut from the

@@ -737,8 +737,9 @@ def test_blind_rotate_step_matches_oracle(eng, oracle, n, spec, w, batch):
 
 @pytest.mark.parametrize("n,spec,w,batch,steps", [(8192, ("bits", 30, 4), 16, 9, 3), (2048, ("bits", 30, 2), 30, 17, 2), (16384, ("bits", 30, 3), 16, 2, 1),
                                                   (32768, ("bits", 30, 2), 16, 2, 2), (4096, ("bits", 40, 2), 20, 3, 3), (2048, ("bits", 60, 2), 32, 2, 2),
-                                                  (256, ("bits", 250, 1), 64, 2, 2), (2048, ("bits", 64, 2), 32, 2, 3)])
-@pytest.mark.parametrize("fused", [True, False, "single", "containers"])
+                                                  (256, ("bits", 250, 1), 64, 2, 2), (2048, ("bits", 64, 2), 32, 2, 3),
+                                                  (16384, ("bits", 40, 2), 20, 2, 2), (16384, ("bits", 60, 1), 32, 1, 3)])      # three-array / split kernels
+@pytest.mark.parametrize("fused", [True, False, "single", "containers", "split"])
 def test_blind_rotate_loop_matches_oracle(eng, oracle, monkeypatch, n, spec, w, batch, steps, fused):
     """fhe_blind_rotate: `steps` external products with a different RGSW row set and different shifts per step; the fused
     one-launch-per-step path (ping-pong buffers, odd and even step counts; digit transforms two at a time -- the default where
@@ -747,6 +748,8 @@ def test_blind_rotate_loop_matches_oracle(eng, oracle, monkeypatch, n, spec, w, 
         monkeypatch.setenv("FHE_HIP_NO_FUSED_BLIND_ROTATE", "1")
     elif fused == "single":
         monkeypatch.setenv("FHE_HIP_NO_PAIRED_TRANSFORMS", "1")
+    elif fused == "split":          # 8-byte residues at N = 2^14: two workgroups per limb instead of one with three live arrays
+        monkeypatch.setenv("FHE_HIP_SPLIT_KEYSWITCH", "1")
     elif fused == "containers":     # fused steps, accumulators ping-pong through the caller's container buffers instead of the compact workspace
         monkeypatch.setenv("FHE_HIP_NO_COMPACT_BLIND_ROTATE", "1")
     moduli = _moduli(spec, n); L = len(moduli)
@@ -1159,13 +1162,17 @@ def test_squaring_forms_match_oracle(eng, oracle, monkeypatch, n, spec, batch, s
 
 
 @pytest.mark.parametrize("n,spec,w,batch", [(16384, ("bits", 40, 2), 16, 2), (16384, ("bits", 60, 1), 32, 1), (16384, ("bits", 64, 1), 32, 2), (32768, ("bits", 30, 1), 16, 1)])
-@pytest.mark.parametrize("two_launch", [True, False])
-def test_tensor_product_without_the_one_launch_kernel(eng, oracle, monkeypatch, n, spec, w, batch, two_launch):
+@pytest.mark.parametrize("forms", ["default", "three-launch", "split-keyswitch"])
+def test_tensor_product_without_the_one_launch_kernel(eng, oracle, monkeypatch, n, spec, w, batch, forms):
     """Sizes whose four transformed operands do not fit the register file (8-byte residues at N = 2^14, N = 2^15): the tensor product runs
     as NTT(b0), NTT(b1) into a compact workspace + one launch for the rest (7 transforms), or with FHE_HIP_NO_TWO_LAUNCH_CT=1 as
-    multiply + multiply + two-product kernel (11 transforms).  Both equal the oracle, alone and inside fhe_ct_multiply_relin."""
-    if not two_launch:
+    multiply + multiply + two-product kernel (11 transforms); the key switch of the 8-byte residues at N = 2^14 as one workgroup per limb
+    with three live arrays, or with FHE_HIP_SPLIT_KEYSWITCH=1 in the split form.  All equal the oracle, alone and inside
+    fhe_ct_multiply_relin / fhe_ct_relinearize."""
+    if forms == "three-launch":
         monkeypatch.setenv("FHE_HIP_NO_TWO_LAUNCH_CT", "1")
+    if forms == "split-keyswitch":
+        monkeypatch.setenv("FHE_HIP_SPLIT_KEYSWITCH", "1")
     moduli = _moduli(spec, n); L = len(moduli)
     e = eng.RnsNttEngine(n, moduli); rp = oracle.RnsPlan(n, moduli)
     a0, a1, b0, b1 = (rns_poly(s, moduli, n, batch) for s in (71, 72, 73, 74))
@@ -1185,6 +1192,11 @@ def test_tensor_product_without_the_one_launch_kernel(eng, oracle, monkeypatch, 
     assert np.array_equal(c[1].download(a0.shape), w1)
     for buf, src in zip(d, (a0, a1, b0, b1)):
         assert np.array_equal(buf.download(a0.shape), src)
+    r = [_up(eng, x) for x in t]                                 # the stand-alone key switch (container operands, in place)
+    e.relinearize(rk, r[0], r[1], r[2], batch)
+    assert np.array_equal(r[0].download(a0.shape), w0)
+    assert np.array_equal(r[1].download(a0.shape), w1)
+    assert np.array_equal(r[2].download(a0.shape), t[2])
 
 
 @pytest.mark.parametrize("n,spec,batch", [(8192, ("bits", 30, 4), 7), (4096, ("bits", 40, 2), 3), (2048, ("bits", 60, 2), 2), (256, ("bits", 250, 1), 3), (2048, ("bits", 64, 2), 2)])

@@ -127,7 +127,8 @@ def test_f52_n16384_instance(resources):
     # bytes per lane today: 160 / 216 / 360; ntt_ct_a_kernel 164 (compact outputs) / 644 (container outputs: the compiler parks the
     # canonical a-side in scratch across the inverse transform + container store, one store and one load per value)
     # ntt_keyswitch3_kernel 444 / 464 (both accumulators + the digit polynomial: about one accumulator's worth is parked per digit)
-    bounds = {"ntt_mac2_kernel": 200, "ntt_keyswitch_kernel": 260, "ntt_extprod_kernel": 420, "ntt_ct_a_kernel": 700, "ntt_keyswitch3_kernel": 520}
+    bounds = {"ntt_mac2_kernel": 200, "ntt_keyswitch_kernel": 260, "ntt_extprod_kernel": 420, "ntt_ct_a_kernel": 700, "ntt_keyswitch3_kernel": 520,
+              "ntt_extprod3_kernel": 720}      # 660 today
     for name, cap in bounds.items():
         for k in _all(kernels, name):
             assert k["vgprs"] <= 256 and k["occupancy"] >= 2 and k.get("scratch", 0) <= cap, (name, k)
