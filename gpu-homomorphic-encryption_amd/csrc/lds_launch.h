@@ -18,10 +18,11 @@ constexpr bool lds_ct_fused(int elem_bytes, int log_n) { return elem_bytes == 4 
 // key switching: 4-byte residues run one workgroup per (ciphertext, limb); 8-byte residues and 1024-thread blocks (N = 2^15)
 // two, one per key half (three live arrays instead of four)
 constexpr bool lds_keyswitch_split(int elem_bytes, int log_n) { return elem_bytes == 8 || log_n >= 15; }
-// ... except 8-byte residues at N = 2^14 (one 512-thread workgroup per CU either way), where ONE workgroup per limb with both
-// accumulators and the digit polynomial live (ntt_keyswitch3_kernel: half the transforms, ~450 bytes per lane parked in scratch) beats
-// the split form by 5-8 % on one MI355X; LdsArgs::joint3 selects it (the host clears it under FHE_HIP_SPLIT_KEYSWITCH=1, a testing aid)
-constexpr bool lds_keyswitch_joint3(int elem_bytes, int log_n) { return elem_bytes == 8 && log_n == 14; }
+// ... unless LdsArgs::joint3 asks for ONE workgroup per limb with both accumulators and the digit polynomial live
+// (ntt_keyswitch3_kernel / ntt_extprod3_kernel: half the transforms, ~450-660 bytes per lane parked in scratch at N = 2^14), which exists
+// for every LDS-resident size of the 8-byte residues; the host decides where it is used (use_joint3 in fhe_hip.hip; never under
+// FHE_HIP_SPLIT_KEYSWITCH=1, a testing aid)
+constexpr bool lds_keyswitch_joint3(int elem_bytes, int log_n) { return elem_bytes == 8 && log_n <= 14; }
 
 // key switching / external product in the one-workgroup-per-limb form: twiddle tables copied into LDS for 4-byte residues up
 // to N = 2^13 (exchange buffer + table = 65 KiB per workgroup, still two workgroups per CU).  Interleaved A/B on one MI355X
