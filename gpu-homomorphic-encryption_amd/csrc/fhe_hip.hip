@@ -693,11 +693,18 @@ static bool use_joint3(const fhe_rns_ntt *h, bool extprod) {
     if (h->width == FHE_WIDTH_52) return extprod || h->log_n >= 13;
     return h->log_n >= 12;
 }
-// tensor product where the one-launch kernel does not exist (8-byte residues at N = 2^14, N = 2^15): workspace for the transformed
-// b-side of the two-launch form (ntt_forward_compact_kernel + ntt_ct_a_kernel)
+// Tensor product in two launches (ntt_forward_compact_kernel + ntt_ct_a_kernel, workspace for the transformed b-side) instead of the
+// one-launch kernel: always where that kernel does not exist (8-byte residues at N = 2^14, N = 2^15), and for the 8-byte residues
+// where the interleaved A/B favoured it (one MI355X, batch 1024, N = 8192 / 4096): the FP64 field (tensor product +16 / +25 %, full
+// multiply +6 / +12 %) and the stand-alone tensor product of the full-range 64-bit field (+10 / +14 %); the lazy 64-bit field keeps
+// its one-launch kernel (two launches: -9 % / +-0).  The squaring forms stay on the one-launch kernel (5 transforms).
 static int ct_workspace(fhe_rns_ntt *h, fhe_dev::LdsArgs &A) {
     const int eb = h->width == FHE_WIDTH_32 ? 4 : 8;
-    if (h->no_two_launch_ct || fhe_dev::lds_ct_fused(eb, (int)h->log_n)) return FHE_OK;
+    if (h->no_two_launch_ct || !fhe_dev::lds_ct_two_launch(eb, (int)h->log_n)) return FHE_OK;
+    if (fhe_dev::lds_ct_fused(eb, (int)h->log_n)) {
+        const bool want = h->log_n >= 12 && !A.square && (h->width == FHE_WIDTH_52 || (h->width == FHE_WIDTH_64X && !A.compact_c2));
+        if (!want) return FHE_OK;
+    }
     int rc = ensure_ws(h, 2 * (size_t)A.polys * h->n * eb); if (rc) return rc;
     A.ws = h->d_ws;
     return FHE_OK;

@@ -57,7 +57,20 @@ void CAT(lds_launch_, FHE_FIELD, FHE_LOGN)(const LdsArgs &A) {
                                    (const char *)A.b0, limbs, A.L, A.b_polys ? 1u : 0u);
             break;
         case LDS_CT_MULTIPLY:
-            if constexpr (lds_ct_fused(sizeof(typename F::E), LOGN)) {
+            if (A.ws) {                  // two launches: the b-side transforms into the workspace, then one workgroup per (ciphertext, limb) does the rest
+                if constexpr (lds_ct_two_launch(sizeof(typename F::E), LOGN)) {
+                    using E = typename F::E;
+                    E *w0 = (E *)A.ws, *w1 = w0 + (size_t)A.polys * (1u << LOGN);
+                    hipLaunchKernelGGL((ntt_forward_compact_kernel<F, LOGN, MULT_MINW>), dim3(A.polys, 2), block, 0, A.stream, w0, w1,
+                                       (const char *)A.b0, (const char *)A.b1, limbs, A.L);
+                    if (A.compact_c2)
+                        hipLaunchKernelGGL((ntt_ct_a_kernel<F, LOGN, MULT_MINW, true>), grid, block, 0, A.stream, (char *)A.r0, (char *)A.r1, (char *)A.r2,
+                                           (const char *)A.a0, (const char *)A.a1, (const E *)w0, (const E *)w1, limbs, A.L);
+                    else
+                        hipLaunchKernelGGL((ntt_ct_a_kernel<F, LOGN, MULT_MINW, false>), grid, block, 0, A.stream, (char *)A.r0, (char *)A.r1, (char *)A.r2,
+                                           (const char *)A.a0, (const char *)A.a1, (const E *)w0, (const E *)w1, limbs, A.L);
+                }
+            } else if constexpr (lds_ct_fused(sizeof(typename F::E), LOGN)) {
                 if (A.compact_c2) {
                     hipLaunchKernelGGL((ntt_ct_multiply_kernel<F, LOGN, false, true>), grid, block, 0, A.stream, (char *)A.r0, (char *)A.r1,
                                        (char *)A.r2, (const char *)A.a0, (const char *)A.a1, (const char *)A.b0, (const char *)A.b1,
@@ -70,17 +83,6 @@ void CAT(lds_launch_, FHE_FIELD, FHE_LOGN)(const LdsArgs &A) {
                     hipLaunchKernelGGL((ntt_ct_multiply_kernel<F, LOGN>), grid, block, 0, A.stream, (char *)A.r0, (char *)A.r1,
                                        (char *)A.r2, (const char *)A.a0, (const char *)A.a1, (const char *)A.b0, (const char *)A.b1,
                                        limbs, A.L);
-            } else if (A.ws) {           // two launches: the b-side transforms into the workspace, then one workgroup per (ciphertext, limb) does the rest
-                using E = typename F::E;
-                E *w0 = (E *)A.ws, *w1 = w0 + (size_t)A.polys * (1u << LOGN);
-                hipLaunchKernelGGL((ntt_forward_compact_kernel<F, LOGN, MULT_MINW>), dim3(A.polys, 2), block, 0, A.stream, w0, w1,
-                                   (const char *)A.b0, (const char *)A.b1, limbs, A.L);
-                if (A.compact_c2)
-                    hipLaunchKernelGGL((ntt_ct_a_kernel<F, LOGN, MULT_MINW, true>), grid, block, 0, A.stream, (char *)A.r0, (char *)A.r1, (char *)A.r2,
-                                       (const char *)A.a0, (const char *)A.a1, (const E *)w0, (const E *)w1, limbs, A.L);
-                else
-                    hipLaunchKernelGGL((ntt_ct_a_kernel<F, LOGN, MULT_MINW, false>), grid, block, 0, A.stream, (char *)A.r0, (char *)A.r1, (char *)A.r2,
-                                       (const char *)A.a0, (const char *)A.a1, (const E *)w0, (const E *)w1, limbs, A.L);
             } else if (A.compact_c2) {   // three launches with compact outputs
                 hipLaunchKernelGGL((ntt_multiply_kernel<F, LOGN, MULT_MINW, false, true>), grid, block, 0, A.stream, (char *)A.r0,
                                    (const char *)A.a0, (const char *)A.b0, limbs, A.L, 0u);

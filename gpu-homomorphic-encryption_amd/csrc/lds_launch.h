@@ -15,6 +15,9 @@ enum LdsOp { LDS_FORWARD = 0, LDS_INVERSE = 1, LDS_MULTIPLY = 2, LDS_CT_MULTIPLY
 // set: NTT(b0), NTT(b1) into the compact workspace, then everything else; 7 transforms) or, without a workspace (testing aid
 // FHE_HIP_NO_TWO_LAUNCH_CT=1), multiply(c0), multiply(c2) and the two-product kernel for c1 (three launches, 11 transforms)
 constexpr bool lds_ct_fused(int elem_bytes, int log_n) { return elem_bytes == 4 ? log_n <= 14 : log_n <= 13; }   // 1024-thread blocks cap a thread at 128 VGPRs
+// the two-launch form exists wherever the one-launch kernel does not, and for every size of the 8-byte residues (whose one-launch
+// kernel holds four 64-register arrays and parks 1.1-1.3 KB per lane in scratch when it writes containers); LdsArgs::ws selects it
+constexpr bool lds_ct_two_launch(int elem_bytes, int log_n) { return elem_bytes == 8 || !lds_ct_fused(elem_bytes, log_n); }
 // key switching: 4-byte residues run one workgroup per (ciphertext, limb); 8-byte residues and 1024-thread blocks (N = 2^15)
 // two, one per key half (three live arrays instead of four)
 constexpr bool lds_keyswitch_split(int elem_bytes, int log_n) { return elem_bytes == 8 || log_n >= 15; }

@@ -1161,15 +1161,17 @@ def test_squaring_forms_match_oracle(eng, oracle, monkeypatch, n, spec, batch, s
     assert np.array_equal(dA0.download(a0.shape), rp.polymul(a0, a0, threads=8))
 
 
-@pytest.mark.parametrize("n,spec,w,batch", [(16384, ("bits", 40, 2), 16, 2), (16384, ("bits", 60, 1), 32, 1), (16384, ("bits", 64, 1), 32, 2), (32768, ("bits", 30, 1), 16, 1)])
-@pytest.mark.parametrize("forms", ["default", "three-launch", "split-keyswitch"])
+@pytest.mark.parametrize("n,spec,w,batch", [(16384, ("bits", 40, 2), 16, 2), (16384, ("bits", 60, 1), 32, 1), (16384, ("bits", 64, 1), 32, 2), (32768, ("bits", 30, 1), 16, 1),
+                                            (8192, ("bits", 40, 2), 20, 3), (4096, ("bits", 64, 2), 32, 2), (4096, ("bits", 43, 1), 16, 5)])   # two-launch by choice (A/B)
+@pytest.mark.parametrize("forms", ["default", "no-two-launch", "split-keyswitch"])
 def test_tensor_product_without_the_one_launch_kernel(eng, oracle, monkeypatch, n, spec, w, batch, forms):
     """Sizes whose four transformed operands do not fit the register file (8-byte residues at N = 2^14, N = 2^15): the tensor product runs
     as NTT(b0), NTT(b1) into a compact workspace + one launch for the rest (7 transforms), or with FHE_HIP_NO_TWO_LAUNCH_CT=1 as
-    multiply + multiply + two-product kernel (11 transforms); the key switch of the 8-byte residues at N = 2^14 as one workgroup per limb
+    multiply + multiply + two-product kernel (11 transforms) -- or, at the smaller sizes of the 8-byte fields where the two-launch form is
+    merely the faster choice, as the one-launch kernel; the key switch of the 8-byte residues at N = 2^14 as one workgroup per limb
     with three live arrays, or with FHE_HIP_SPLIT_KEYSWITCH=1 in the split form.  All equal the oracle, alone and inside
     fhe_ct_multiply_relin / fhe_ct_relinearize."""
-    if forms == "three-launch":
+    if forms == "no-two-launch":
         monkeypatch.setenv("FHE_HIP_NO_TWO_LAUNCH_CT", "1")
     if forms == "split-keyswitch":
         monkeypatch.setenv("FHE_HIP_SPLIT_KEYSWITCH", "1")
