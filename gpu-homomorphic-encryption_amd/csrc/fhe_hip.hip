@@ -691,7 +691,7 @@ static bool use_joint3(const fhe_rns_ntt *h, bool extprod) {
     const int eb = h->width == FHE_WIDTH_32 ? 4 : 8;
     if (h->split_keyswitch || !fhe_dev::lds_keyswitch_joint3(eb, (int)h->log_n)) return false;
     if (h->width == FHE_WIDTH_52) return extprod || h->log_n >= 13;
-    return h->log_n >= 12;
+    return h->log_n >= 12;   // (4-byte residues reach here only at N = 2^15)
 }
 // Tensor product in two launches (ntt_forward_compact_kernel + ntt_ct_a_kernel, workspace for the transformed b-side) instead of the
 // one-launch kernel: always where that kernel does not exist (8-byte residues at N = 2^14, N = 2^15), and for the 8-byte residues

@@ -23,9 +23,10 @@ constexpr bool lds_ct_two_launch(int elem_bytes, int log_n) { return elem_bytes 
 constexpr bool lds_keyswitch_split(int elem_bytes, int log_n) { return elem_bytes == 8 || log_n >= 15; }
 // ... unless LdsArgs::joint3 asks for ONE workgroup per limb with both accumulators and the digit polynomial live
 // (ntt_keyswitch3_kernel / ntt_extprod3_kernel: half the transforms, ~450-660 bytes per lane parked in scratch at N = 2^14), which exists
-// for every LDS-resident size of the 8-byte residues; the host decides where it is used (use_joint3 in fhe_hip.hip; never under
+// for every LDS-resident size of the 8-byte residues and for 4-byte residues at N = 2^15 (1024-thread workgroups capped at 128 VGPRs:
+// relinearisation +38 %, blind rotation +48 % over the split form); the host decides where it is used (use_joint3 in fhe_hip.hip; never under
 // FHE_HIP_SPLIT_KEYSWITCH=1, a testing aid)
-constexpr bool lds_keyswitch_joint3(int elem_bytes, int log_n) { return elem_bytes == 8 && log_n <= 14; }
+constexpr bool lds_keyswitch_joint3(int elem_bytes, int log_n) { return (elem_bytes == 8 && log_n <= 14) || (elem_bytes == 4 && log_n == 15); }
 
 // key switching / external product in the one-workgroup-per-limb form: twiddle tables copied into LDS for 4-byte residues up
 // to N = 2^13 (exchange buffer + table = 65 KiB per workgroup, still two workgroups per CU).  Interleaved A/B on one MI355X
