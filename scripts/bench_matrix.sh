@@ -38,6 +38,19 @@ run --steps 10 --warmup 2 --op fwdinv   --batch 1024 --bits 40 --limbs 3
 run --steps 10 --warmup 2 --op multiply --batch 1024 --bits 60 --limbs 2
 run --steps 10 --warmup 2 --op ct       --batch 1024 --bits 60 --limbs 2
 run --steps 5  --warmup 1 --op ctrelin  --batch 256 --bits 60 --limbs 2
+run --steps 5  --warmup 1 --op relin    --batch 512 --bits 60 --limbs 2 --decomp-bits 32
+run --steps 5  --warmup 1 --op blindrotate --batch 512 --bits 60 --limbs 2 --decomp-bits 32
+run --steps 10 --warmup 2 --op ct       --batch 1024 --bits 40 --limbs 3
+run --steps 5  --warmup 1 --op ctrelin  --batch 1024 --bits 40 --limbs 3 --decomp-bits 20
+run --steps 5  --warmup 1 --op relin    --batch 512 --bits 40 --limbs 3 --decomp-bits 20
+# configs[3] shape with 8-byte residues: key switch alone, w = 20, 60-bit base; N = 2^15 on the 4-byte residues
+run --steps 5  --warmup 1 --op relin    --batch 128 --n 16384 --limbs 6 --bits 40
+run --steps 5  --warmup 1 --op ctrelin  --batch 128 --n 16384 --limbs 6 --bits 40 --decomp-bits 20
+run --steps 5  --warmup 1 --op blindrotate --batch 128 --n 16384 --limbs 6 --bits 40
+run --steps 5  --warmup 1 --op ctrelin  --batch 128 --n 16384 --limbs 3 --bits 60 --decomp-bits 32
+run --steps 5  --warmup 1 --op relin    --batch 128 --n 32768 --limbs 4 --bits 30
+run --steps 5  --warmup 1 --op ctrelin  --batch 128 --n 32768 --limbs 4 --bits 30
+run --steps 5  --warmup 1 --op blindrotate --batch 128 --n 32768 --limbs 4 --bits 30
 # 64-bit primes: full-range 64-bit class (FHE_WIDTH_64X)
 run --steps 10 --warmup 2 --op multiply --batch 1024 --bits 64 --limbs 2
 run --steps 10 --warmup 2 --op multiply --batch 256 --bits 64 --limbs 2
