@@ -1,5 +1,5 @@
 // lds_inst.hip -- one (field, LOGN) instance of the LDS-resident kernels.
-// Compile with -DFHE_FIELD=F32|F64 -DFHE_LOGN=11..15.
+// Compile with -DFHE_FIELD=F32|F52|F64|F64X -DFHE_LOGN=11..15 (the Makefile lists the instances).
 #include "lds_launch.h"
 #include "ntt_lds.hip.h"
 
