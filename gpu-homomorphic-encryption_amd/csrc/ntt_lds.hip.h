@@ -486,6 +486,45 @@ __device__ __forceinline__ void load_src(const char *__restrict__ base, size_t p
     else load_A<F, LOGN>(base + poly_index * (NttCfg<LOGN>::N * 32), tid, x);
 }
 
+// 16-byte loads of table rows through a buffer descriptor: SGPR base + ONE shared VGPR offset (tid * 16) + a scalar offset per load
+// (`buffer_load_dwordx4 v, voff, s[rsrc], soff offen`).  With flat pointers every chunk of a key row needs its own 64-bit VGPR address
+// (the chunk stride exceeds the 12-bit immediate), the compiler hoists those out of the digit loops and, in the register-starved
+// kernels, spills them: 34 address pairs in the three-array key switch.  Offsets are 32-bit: the host keeps packed tables below 4 GiB.
+struct TableBuf {
+    __amdgpu_buffer_rsrc_t r;
+    __device__ __forceinline__ explicit TableBuf(const void *base) : r(__builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, 0xffffffffu, 0x00020000)) {}
+    template <class VecE> __device__ __forceinline__ VecE load16(uint32_t voff, uint32_t soff) const {
+        static_assert(sizeof(VecE) == 16, "one 16-byte lane load");
+        return __builtin_bit_cast(VecE, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+    }
+    // one residue: the low word(s) of a container (an integer, as F::load_low reads it) or a compact slot (the field's own type)
+    template <class F, bool COMPACT> __device__ __forceinline__ typename F::E load_residue(uint32_t voff, uint32_t soff) const {
+        using E = typename F::E;
+        constexpr int AUX = 0;                   // temporal: these loads serve operands that several workgroups re-read (measured: nt costs 2-7 % on relinearisation)
+        if constexpr (sizeof(E) == 4) return __builtin_bit_cast(uint32_t, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, AUX));
+        else {
+            const uint64_t raw = __builtin_bit_cast(uint64_t, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, AUX));
+            if constexpr (COMPACT) return __builtin_bit_cast(E, raw);
+            else return (E)raw;
+        }
+    }
+};
+// load_src through a descriptor based at the first limb polynomial of a ciphertext component (`poly` = limb index within it): the 32
+// loads of a thread share one VGPR offset, the per-load strides are scalar
+template <class F, int LOGN, bool COMPACT>
+__device__ __forceinline__ void load_src_buf(const TableBuf &B, uint32_t poly, uint32_t tid, typename F::E (&x)[32]) {
+    using C = NttCfg<LOGN>;
+    constexpr uint32_t STRIDE = COMPACT ? sizeof(typename F::E) : 32;
+    const uint32_t voff = tid * STRIDE, base = poly * (C::N * STRIDE);
+#pragma unroll
+    for (int r = 0; r < 32; r++) x[r] = B.template load_residue<F, COMPACT>(voff, base + r * (C::T * STRIDE));
+}
+// one polynomial by its own base pointer (uniform per workgroup)
+template <class F, int LOGN, bool COMPACT>
+__device__ __forceinline__ void load_poly_buf(const void *poly, uint32_t tid, typename F::E (&x)[32]) {
+    load_src_buf<F, LOGN, COMPACT>(TableBuf(poly), 0, tid, x);
+}
+
 // Every lane of a wave holds the residue `o` of one of 64 consecutive containers starting at half-container `dst`: lane pairs store
 // the value half and the zero half of each container (two instructions of 1 KiB consecutive bytes per wave), so the arithmetic that
 // produced `o` runs on all 64 lanes instead of on the even ones of a one-half-container-per-lane kernel.
@@ -946,38 +985,38 @@ ntt_ct_a_kernel(char *__restrict__ c0, char *__restrict__ c1, char *__restrict__
     // CT_FENCE: the compiler may not move the next phase's 32 loads above the transform / store before it (they would be a third
     // live array across it: the kernel spills 600+ bytes per lane without the fences)
 #define CT_FENCE() do { __builtin_amdgcn_sched_barrier(0); asm volatile("" ::: "memory"); } while (0)
-    load_A<F, LOGN>(a0 + off, tid, X);
+    load_poly_buf<F, LOGN, false>(a0 + off, tid, X);
     fwd_core<F, LOGN>(X, lds, tid, P);
     CT_FENCE();
-    load_A_compact<F, LOGN>(B0, tid, Y);
+    load_poly_buf<F, LOGN, true>(B0, tid, Y);
 #pragma unroll
     for (int r = 0; r < 32; r++) { X[r] = F::canon_fwd(X[r], P.q, P.q2, P.qinv); T[r] = F::pw_mul(X[r], Y[r], P.q, P.qinv); }
-    if constexpr (EARLY) load_A_compact<F, LOGN>(B1, tid, Y);     // in flight under the inverse transform of c0 (a third live array)
+    if constexpr (EARLY) load_poly_buf<F, LOGN, true>(B1, tid, Y);     // in flight under the inverse transform of c0 (a third live array)
     else CT_FENCE();
     inv_core<F, LOGN>(T, lds, tid, P, P.ninv_r, P.ninv_r_s, P.ninvw_r, P.ninvw_r_s);
 #pragma unroll
     for (int r = 0; r < 32; r++) T[r] = F::canon_inv(T[r], P.q);
     ct_store<F, LOGN, COMPACT_OUT>(c0, p, lds, tid, T);
     CT_FENCE();
-    if constexpr (!EARLY) load_A_compact<F, LOGN>(B1, tid, Y);
+    if constexpr (!EARLY) load_poly_buf<F, LOGN, true>(B1, tid, Y);
 #pragma unroll
     for (int r = 0; r < 32; r++) T[r] = F::pw_mul(X[r], Y[r], P.q, P.qinv);          // A0 . B1
     CT_FENCE();
-    load_A<F, LOGN>(a1 + off, tid, X);
+    load_poly_buf<F, LOGN, false>(a1 + off, tid, X);
     __syncthreads();
     fwd_core<F, LOGN>(X, lds, tid, P);
     CT_FENCE();
-    load_A_compact<F, LOGN>(B0, tid, Y);
+    load_poly_buf<F, LOGN, true>(B0, tid, Y);
 #pragma unroll
     for (int r = 0; r < 32; r++) { X[r] = F::canon_fwd(X[r], P.q, P.q2, P.qinv); T[r] = F::pw_add(T[r], F::pw_mul(X[r], Y[r], P.q, P.qinv), P.q, P.q2); }
-    if constexpr (EARLY) load_A_compact<F, LOGN>(B1, tid, Y);
+    if constexpr (EARLY) load_poly_buf<F, LOGN, true>(B1, tid, Y);
     else CT_FENCE();
     inv_core<F, LOGN>(T, lds, tid, P, P.ninv_r, P.ninv_r_s, P.ninvw_r, P.ninvw_r_s);
 #pragma unroll
     for (int r = 0; r < 32; r++) T[r] = F::canon_inv(T[r], P.q);
     ct_store<F, LOGN, COMPACT_OUT>(c1, p, lds, tid, T);
     CT_FENCE();
-    if constexpr (!EARLY) load_A_compact<F, LOGN>(B1, tid, Y);
+    if constexpr (!EARLY) load_poly_buf<F, LOGN, true>(B1, tid, Y);
 #pragma unroll
     for (int r = 0; r < 32; r++) T[r] = F::pw_mul(X[r], Y[r], P.q, P.qinv);          // A1 . B1
     CT_FENCE();
@@ -1272,18 +1311,19 @@ ntt_keyswitch3_kernel(char *c0, char *c1, const char *__restrict__ c2, const cha
     E acc0[32], acc1[32], d[32];
 #pragma unroll
     for (int r = 0; r < 32; r++) { acc0[r] = 0; acc1[r] = 0; }
+    const TableBuf KB(kb), KA(ka), C2(c2 + (size_t)b * L * (C::N * (COMPACT ? sizeof(E) : 32)));   // c2 of this ciphertext
+    const uint32_t voff = tid * 16;
     for (uint32_t j = 0; j < L; j++) {
         for (uint32_t k = 0; k < K; k++) {
-            load_src<F, LOGN, COMPACT>(c2, (size_t)b * L + j, tid, d);
+            load_src_buf<F, LOGN, COMPACT>(C2, j, tid, d);
 #pragma unroll
             for (int r = 0; r < 32; r++) d[r] = F::digit(d[r], k * w, w);
             fwd_core<F, LOGN, false, true>(d, lds, tid, P);
             __builtin_amdgcn_sched_barrier(0);   // keep the key loads out of the transform
-            const size_t tbl = ((size_t)(j * K + k) * L + i) * C::N;
-            const VecE *pb = reinterpret_cast<const VecE *>(kb + tbl) + tid, *pa = reinterpret_cast<const VecE *>(ka + tbl) + tid;
+            const uint32_t tbl = (uint32_t)((((size_t)(j * K + k) * L + i) * C::N) * sizeof(E));   // byte offset of the row (< 4 GiB: host)
 #pragma unroll
             for (int c = 0; c < NCH; c++) {
-                const VecE vb = pb[c * C::T], va = pa[c * C::T];
+                const VecE vb = KB.template load16<VecE>(voff, tbl + c * C::T * 16), va = KA.template load16<VecE>(voff, tbl + c * C::T * 16);
 #pragma unroll
                 for (int e = 0; e < VPL; e++) {
                     const int r = c * VPL + e;
@@ -1297,7 +1337,7 @@ ntt_keyswitch3_kernel(char *c0, char *c1, const char *__restrict__ c2, const cha
     F::regroup(acc0, P.q, P.qinv);
     inv_core<F, LOGN, false, true>(acc0, lds, tid, P, P.ninv, P.ninv_s, P.ninvw, P.ninvw_s);
     __builtin_amdgcn_sched_barrier(0);
-    load_src<F, LOGN, COMPACT>(add0, p, tid, d);
+    load_poly_buf<F, LOGN, COMPACT>(add0 + (size_t)p * (C::N * (COMPACT ? sizeof(E) : 32)), tid, d);
 #pragma unroll
     for (int r = 0; r < 32; r++) acc0[r] = F::ew_add(F::canon_inv(acc0[r], P.q), d[r], P.q);
     lds_put<PatA<LOGN>>(lds, tid, acc0);
@@ -1307,7 +1347,7 @@ ntt_keyswitch3_kernel(char *c0, char *c1, const char *__restrict__ c2, const cha
     F::regroup(acc1, P.q, P.qinv);
     __syncthreads();
     inv_core<F, LOGN>(acc1, lds, tid, P, P.ninv, P.ninv_s, P.ninvw, P.ninvw_s);
-    load_src<F, LOGN, COMPACT>(add1, p, tid, d);
+    load_poly_buf<F, LOGN, COMPACT>(add1 + (size_t)p * (C::N * (COMPACT ? sizeof(E) : 32)), tid, d);
 #pragma unroll
     for (int r = 0; r < 32; r++) acc1[r] = F::ew_add(F::canon_inv(acc1[r], P.q), d[r], P.q);
     lds_put<PatA<LOGN>>(lds, tid, acc1);
@@ -1324,12 +1364,24 @@ ntt_keyswitch3_kernel(char *c0, char *c1, const char *__restrict__ c2, const cha
 // 2*L*K forward + 2 inverse transforms per workgroup; HBM traffic per ciphertext: read in0, in1 (re-reads by the L workgroups of a
 // ciphertext are XCD-L2 / Infinity-Cache hits, same block map as the key-switch kernel) + write out0, out1 = 4 * S.
 // SPLIT as for the key-switch kernel: two workgroups per (b, i), one per output component.
+template <class F, int LOGN>
+__device__ __forceinline__ void rotate_through_lds(typename F::E *lds, uint32_t tid, uint32_t a, typename F::E qj, typename F::E (&x)[32]);
+template <class F, int LOGN, bool COMPACT = false>      // the same through a descriptor based at the accumulator's first limb (load_src_buf)
+__device__ __forceinline__ void load_monomial_A_buf(const TableBuf &B, uint32_t limb, typename F::E *lds, uint32_t tid, uint32_t a,
+                                                    typename F::E qj, typename F::E (&x)[32]) {
+    load_src_buf<F, LOGN, COMPACT>(B, limb, tid, x);
+    rotate_through_lds<F, LOGN>(lds, tid, a, qj, x);
+}
 template <class F, int LOGN, bool COMPACT = false>
 __device__ __forceinline__ void load_monomial_A(const char *__restrict__ base, size_t poly_index, typename F::E *lds, uint32_t tid, uint32_t a,
                                                 typename F::E qj, typename F::E (&x)[32]) {
+    load_src<F, LOGN, COMPACT>(base, poly_index, tid, x);   // p[i], i = tid + r*T
+    rotate_through_lds<F, LOGN>(lds, tid, a, qj, x);
+}
+template <class F, int LOGN>
+__device__ __forceinline__ void rotate_through_lds(typename F::E *lds, uint32_t tid, uint32_t a, typename F::E qj, typename F::E (&x)[32]) {
     using C = NttCfg<LOGN>;
     using E = typename F::E;
-    load_src<F, LOGN, COMPACT>(base, poly_index, tid, x);   // p[i], i = tid + r*T
     __syncthreads();                                // the previous transform's last reads of the exchange buffer are over
     lds_put<PatA<LOGN>>(lds, tid, x);
     __syncthreads();
@@ -1479,22 +1531,22 @@ ntt_extprod3_kernel(char *__restrict__ out0, char *__restrict__ out1, const char
     E acc0[32], acc1[32], d[32];
 #pragma unroll
     for (int r = 0; r < 32; r++) { acc0[r] = 0; acc1[r] = 0; }
+    const uint32_t voff = tid * 16;
     for (uint32_t c = 0; c < 2; c++) {
-        const char *src = c ? in1 : in0;
-        const E *kb = c ? kb1 : kb0, *ka = c ? ka1 : ka0;
+        const TableBuf KB(c ? kb1 : kb0), KA(c ? ka1 : ka0), SRC((c ? in1 : in0) + (size_t)b * L * (C::N * 32));   // this accumulator's component c
         for (uint32_t j = 0; j < L; j++) {
             const E qj = limbs[j].q;
             for (uint32_t k = 0; k < K; k++) {
-                load_monomial_A<F, LOGN>(src, (size_t)b * L + j, lds, tid, a, qj, d);
+                if constexpr (__is_same(typename F::E, double)) load_monomial_A<F, LOGN>(c ? in1 : in0, (size_t)b * L + j, lds, tid, a, qj, d);
+                else load_monomial_A_buf<F, LOGN>(SRC, j, lds, tid, a, qj, d);
 #pragma unroll
                 for (int r = 0; r < 32; r++) d[r] = F::digit(d[r], k * w, w);
                 fwd_core<F, LOGN, false, true>(d, lds, tid, P);
                 __builtin_amdgcn_sched_barrier(0);   // keep the key loads out of the transform
-                const size_t tbl = ((size_t)(j * K + k) * L + i) * C::N;
-                const VecE *pb = reinterpret_cast<const VecE *>(kb + tbl) + tid, *pa = reinterpret_cast<const VecE *>(ka + tbl) + tid;
+                const uint32_t tbl = (uint32_t)((((size_t)(j * K + k) * L + i) * C::N) * sizeof(E));
 #pragma unroll
                 for (int ch = 0; ch < NCH; ch++) {
-                    const VecE vb = pb[ch * C::T], va = pa[ch * C::T];
+                    const VecE vb = KB.template load16<VecE>(voff, tbl + ch * C::T * 16), va = KA.template load16<VecE>(voff, tbl + ch * C::T * 16);
 #pragma unroll
                     for (int e = 0; e < VPL; e++) {
                         const int r = ch * VPL + e;
@@ -1510,7 +1562,7 @@ ntt_extprod3_kernel(char *__restrict__ out0, char *__restrict__ out1, const char
     }
     inv_core<F, LOGN, false, true>(acc0, lds, tid, P, P.ninv, P.ninv_s, P.ninvw, P.ninvw_s);
     __builtin_amdgcn_sched_barrier(0);
-    load_A<F, LOGN>(in0 + (size_t)p * (C::N * 32), tid, d);
+    load_poly_buf<F, LOGN, false>(in0 + (size_t)p * (C::N * 32), tid, d);
 #pragma unroll
     for (int r = 0; r < 32; r++) acc0[r] = F::ew_add(F::canon_inv(acc0[r], P.q), d[r], P.q);
     lds_put<PatA<LOGN>>(lds, tid, acc0);
@@ -1519,7 +1571,7 @@ ntt_extprod3_kernel(char *__restrict__ out0, char *__restrict__ out1, const char
     __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
     inv_core<F, LOGN>(acc1, lds, tid, P, P.ninv, P.ninv_s, P.ninvw, P.ninvw_s);
-    load_A<F, LOGN>(in1 + (size_t)p * (C::N * 32), tid, d);
+    load_poly_buf<F, LOGN, false>(in1 + (size_t)p * (C::N * 32), tid, d);
 #pragma unroll
     for (int r = 0; r < 32; r++) acc1[r] = F::ew_add(F::canon_inv(acc1[r], P.q), d[r], P.q);
     lds_put<PatA<LOGN>>(lds, tid, acc1);
@@ -1538,10 +1590,11 @@ __device__ __forceinline__ void mac_keys(typename F::E (&acc0)[32], typename F::
     using E = typename F::E;
     constexpr int VPL = 16 / sizeof(E), NCH = 32 / VPL;
     typedef E VecE __attribute__((ext_vector_type(VPL)));
-    const VecE *pb = reinterpret_cast<const VecE *>(kb + tbl) + tid, *pa = reinterpret_cast<const VecE *>(ka + tbl) + tid;
+    const TableBuf KB(kb), KA(ka);                          // SGPR descriptors + one shared VGPR offset: no per-chunk 64-bit addresses
+    const uint32_t voff = tid * 16, row = (uint32_t)(tbl * sizeof(E));
 #pragma unroll
     for (int c = 0; c < NCH; c++) {
-        const VecE vb = pb[c * T], va = pa[c * T];
+        const VecE vb = KB.template load16<VecE>(voff, row + c * T * 16), va = KA.template load16<VecE>(voff, row + c * T * 16);
 #pragma unroll
         for (int e = 0; e < VPL; e++) {
             const int r = c * VPL + e;
@@ -1560,11 +1613,12 @@ __device__ __forceinline__ void mac_keys2(typename F::E (&acc0)[32], typename F:
     static_assert(sizeof(E) == 4, "mont_mul2 is a 32-bit field operation");
     constexpr int VPL = 16 / sizeof(E), NCH = 32 / VPL;
     typedef E VecE __attribute__((ext_vector_type(VPL)));
-    const VecE *pb0 = reinterpret_cast<const VecE *>(kb0 + tbl0) + tid, *pa0 = reinterpret_cast<const VecE *>(ka0 + tbl0) + tid;
-    const VecE *pb1 = reinterpret_cast<const VecE *>(kb1 + tbl1) + tid, *pa1 = reinterpret_cast<const VecE *>(ka1 + tbl1) + tid;
+    const TableBuf KB0(kb0), KA0(ka0), KB1(kb1), KA1(ka1);
+    const uint32_t voff = tid * 16, row0 = (uint32_t)(tbl0 * sizeof(E)), row1 = (uint32_t)(tbl1 * sizeof(E));
 #pragma unroll
     for (int c = 0; c < NCH; c++) {
-        const VecE vb0 = pb0[c * T], va0 = pa0[c * T], vb1 = pb1[c * T], va1 = pa1[c * T];
+        const VecE vb0 = KB0.template load16<VecE>(voff, row0 + c * T * 16), va0 = KA0.template load16<VecE>(voff, row0 + c * T * 16);
+        const VecE vb1 = KB1.template load16<VecE>(voff, row1 + c * T * 16), va1 = KA1.template load16<VecE>(voff, row1 + c * T * 16);
 #pragma unroll
         for (int e = 0; e < VPL; e++) {
             const int r = c * VPL + e;
@@ -1615,7 +1669,7 @@ ntt_keyswitch2_kernel(char *c0, char *c1, const char *__restrict__ c2, const cha
     else { b = bid / L; i = bid % L; }
     const uint32_t p = b * L + i;
     const Limb<F> P = limbs[i];
-    const size_t ct2 = (size_t)b * L;                    // first limb polynomial of this ciphertext's c2
+    const TableBuf C2(c2 + (size_t)b * L * (C::N * (COMPACT ? sizeof(E) : 32)));   // descriptor based at the first limb polynomial of this ciphertext's c2
     E acc0[32], acc1[32], d0[32], d1[32];
 #pragma unroll
     for (int r = 0; r < 32; r++) { acc0[r] = 0; acc1[r] = 0; }
@@ -1623,12 +1677,12 @@ ntt_keyswitch2_kernel(char *c0, char *c1, const char *__restrict__ c2, const cha
     uint32_t jk = 0;
     for (; jk + 1 < LK; jk += 2) {
         const uint32_t j0 = jk / K, k0 = jk % K, j1 = (jk + 1) / K, k1 = (jk + 1) % K;
-        load_src<F, LOGN, COMPACT>(c2, ct2 + j1, tid, d1);
+        load_src_buf<F, LOGN, COMPACT>(C2, j1, tid, d1);
         if (j0 == j1) {
 #pragma unroll
             for (int r = 0; r < 32; r++) d0[r] = F::digit(d1[r], k0 * w, w);
         } else {
-            load_src<F, LOGN, COMPACT>(c2, ct2 + j0, tid, d0);
+            load_src_buf<F, LOGN, COMPACT>(C2, j0, tid, d0);
 #pragma unroll
             for (int r = 0; r < 32; r++) d0[r] = F::digit(d0[r], k0 * w, w);
         }
@@ -1639,7 +1693,7 @@ ntt_keyswitch2_kernel(char *c0, char *c1, const char *__restrict__ c2, const cha
     }
     if (jk < LK) {                                        // odd number of digit polynomials: the last one alone
         const uint32_t j0 = jk / K, k0 = jk % K;
-        load_src<F, LOGN, COMPACT>(c2, ct2 + j0, tid, d0);
+        load_src_buf<F, LOGN, COMPACT>(C2, j0, tid, d0);
 #pragma unroll
         for (int r = 0; r < 32; r++) d0[r] = F::digit(d0[r], k0 * w, w);
         fwd_core<F, LOGN, false, true>(d0, lds, tid, P);
@@ -1668,7 +1722,8 @@ ntt_extprod2_kernel(char *__restrict__ out0, char *__restrict__ out1, const char
     const uint32_t p = b * L + i;
     const Limb<F> P = limbs[i];
     const uint32_t a = shifts[b] & (2 * C::N - 1);
-    const size_t ct = (size_t)b * L;                     // first limb polynomial of this accumulator
+    const size_t cbytes = (size_t)b * L * (C::N * (IN_COMPACT ? sizeof(E) : 32));
+    const TableBuf IN0(in0 + cbytes), IN1(in1 + cbytes);   // descriptors based at the first limb polynomial of this accumulator's two components
     E acc0[32], acc1[32], d0[32], d1[32];
 #pragma unroll
     for (int r = 0; r < 32; r++) { acc0[r] = 0; acc1[r] = 0; }
@@ -1676,12 +1731,12 @@ ntt_extprod2_kernel(char *__restrict__ out0, char *__restrict__ out1, const char
     for (uint32_t g = 0; g < G; g += 2) {
         const uint32_t c0i = g / LK, jk0 = g % LK, j0 = jk0 / K, k0 = jk0 % K;
         const uint32_t c1i = (g + 1) / LK, jk1 = (g + 1) % LK, j1 = jk1 / K, k1 = jk1 % K;
-        load_monomial_A<F, LOGN, IN_COMPACT>(c1i ? in1 : in0, ct + j1, lds, tid, a, limbs[j1].q, d1);
+        load_monomial_A_buf<F, LOGN, IN_COMPACT>(c1i ? IN1 : IN0, j1, lds, tid, a, limbs[j1].q, d1);
         if (c0i == c1i && j0 == j1) {
 #pragma unroll
             for (int r = 0; r < 32; r++) d0[r] = F::digit(d1[r], k0 * w, w);
         } else {
-            load_monomial_A<F, LOGN, IN_COMPACT>(c0i ? in1 : in0, ct + j0, lds, tid, a, limbs[j0].q, d0);
+            load_monomial_A_buf<F, LOGN, IN_COMPACT>(c0i ? IN1 : IN0, j0, lds, tid, a, limbs[j0].q, d0);
 #pragma unroll
             for (int r = 0; r < 32; r++) d0[r] = F::digit(d0[r], k0 * w, w);
         }
