@@ -250,7 +250,8 @@ struct fhe_rns_ntt {
     int wide_nl = 0;                    // FHE_WIDTH_256: 64-bit limbs per residue in those kernels (2: q < 2^127, 4: q < 2^255)
     bool wide_tiles = true;             // FHE_HIP_NO_WIDE_TILES=1: every stage as a global-memory pass (cross-check / A-B)
     bool no_square = false, single_transforms = false, global_twiddles = false, check_inputs = false, no_fused_keyswitch = false,
-         no_word_conversions = false, no_fused_blind_rotate = false, no_fused_ct_relin = false, no_compact_blind_rotate = false, no_two_launch_ct = false, split_keyswitch = false;   // environment switches, read once at creation
+         no_word_conversions = false, no_fused_blind_rotate = false, no_fused_ct_relin = false, no_compact_blind_rotate = false, no_two_launch_ct = false, split_keyswitch = false;
+    int ct_form_force = 0;                         // FHE_HIP_CT_FORM: 0 = by field and size, 1 = one-launch tensor product where it exists, 2 = two-launch where it exists   // environment switches, read once at creation
     std::vector<void *> d_tables;
     void *d_ws = nullptr; size_t ws_bytes = 0;
     void *d_ws2 = nullptr; size_t ws2_bytes = 0;   // c2 of the fused multiply + relinearise (compact or containers); separate from d_ws, which the general paths use
@@ -531,6 +532,7 @@ static int create_impl(fhe_rns_ntt **out, uint32_t n, const uint64_t (*moduli)[4
     h->no_compact_blind_rotate = getenv("FHE_HIP_NO_COMPACT_BLIND_ROTATE") != nullptr;
     h->no_two_launch_ct = getenv("FHE_HIP_NO_TWO_LAUNCH_CT") != nullptr;
     h->split_keyswitch = getenv("FHE_HIP_SPLIT_KEYSWITCH") != nullptr;
+    if (const char *m = getenv("FHE_HIP_CT_FORM")) h->ct_form_force = !strcmp(m, "two") ? 2 : !strcmp(m, "one") ? 1 : 0;
     { const char *e = getenv("FHE_HIP_CHECK_INPUTS"); h->check_inputs = e && e[0] == '1'; }
     *out = h;
     return FHE_OK;
@@ -695,15 +697,17 @@ static bool use_joint3(const fhe_rns_ntt *h, bool extprod) {
 }
 // Tensor product in two launches (ntt_forward_compact_kernel + ntt_ct_a_kernel, workspace for the transformed b-side) instead of the
 // one-launch kernel: always where that kernel does not exist (8-byte residues at N = 2^14, N = 2^15), and for the 8-byte residues
-// where the interleaved A/B favoured it (one MI355X, batch 1024, N = 8192 / 4096): the FP64 field (tensor product +16 / +25 %, full
-// multiply +6 / +12 %) and the stand-alone tensor product of the full-range 64-bit field (+10 / +14 %); the lazy 64-bit field keeps
-// its one-launch kernel (two launches: -9 % / +-0).  The squaring forms stay on the one-launch kernel (5 transforms).
+// where the interleaved A/B favoured it (scripts/ab_ct_form.sh, one MI355X, batch 1024, N = 8192 / 4096 / 2048): the FP64 field
+// (tensor product +32 / +35 / +26 %, full multiply +11 / +10 / +2 %) and the stand-alone tensor product of the full-range 64-bit
+// field (+13 / +11 / +12 %; inside the full multiply 0 / -9 / -2 %); the lazy 64-bit field keeps its one-launch kernel (-1 / +6 / -4 %).
+// The squaring forms stay on the one-launch kernel (5 transforms).  FHE_HIP_CT_FORM=one|two forces a form where both exist.
 static int ct_workspace(fhe_rns_ntt *h, fhe_dev::LdsArgs &A) {
     const int eb = h->width == FHE_WIDTH_32 ? 4 : 8;
     if (h->no_two_launch_ct || !fhe_dev::lds_ct_two_launch(eb, (int)h->log_n)) return FHE_OK;
     if (fhe_dev::lds_ct_fused(eb, (int)h->log_n)) {
-        const bool want = h->log_n >= 12 && !A.square && (h->width == FHE_WIDTH_52 || (h->width == FHE_WIDTH_64X && !A.compact_c2));
-        if (!want) return FHE_OK;
+        bool want = h->width == FHE_WIDTH_52 || (h->width == FHE_WIDTH_64X && !A.compact_c2);
+        if (h->ct_form_force) want = h->ct_form_force == 2;       // FHE_HIP_CT_FORM=one|two (A/B, cross-check)
+        if (!want || A.square) return FHE_OK;
     }
     int rc = ensure_ws(h, 2 * (size_t)A.polys * h->n * eb); if (rc) return rc;
     A.ws = h->d_ws;

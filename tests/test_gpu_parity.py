@@ -1162,8 +1162,9 @@ def test_squaring_forms_match_oracle(eng, oracle, monkeypatch, n, spec, batch, s
 
 
 @pytest.mark.parametrize("n,spec,w,batch", [(16384, ("bits", 40, 2), 16, 2), (16384, ("bits", 60, 1), 32, 1), (16384, ("bits", 64, 1), 32, 2), (32768, ("bits", 30, 1), 16, 1),
-                                            (8192, ("bits", 40, 2), 20, 3), (4096, ("bits", 64, 2), 32, 2), (4096, ("bits", 43, 1), 16, 5)])   # two-launch by choice (A/B)
-@pytest.mark.parametrize("forms", ["default", "no-two-launch", "split-keyswitch"])
+                                            (8192, ("bits", 40, 2), 20, 3), (4096, ("bits", 64, 2), 32, 2), (4096, ("bits", 43, 1), 16, 5),   # two-launch by choice (A/B)
+                                            (2048, ("bits", 40, 3), 20, 4), (2048, ("bits", 60, 2), 32, 3)])
+@pytest.mark.parametrize("forms", ["default", "no-two-launch", "split-keyswitch", "two-launch"])
 def test_tensor_product_without_the_one_launch_kernel(eng, oracle, monkeypatch, n, spec, w, batch, forms):
     """Sizes whose four transformed operands do not fit the register file (8-byte residues at N = 2^14, N = 2^15): the tensor product runs
     as NTT(b0), NTT(b1) into a compact workspace + one launch for the rest (7 transforms), or with FHE_HIP_NO_TWO_LAUNCH_CT=1 as
@@ -1175,6 +1176,8 @@ def test_tensor_product_without_the_one_launch_kernel(eng, oracle, monkeypatch, 
         monkeypatch.setenv("FHE_HIP_NO_TWO_LAUNCH_CT", "1")
     if forms == "split-keyswitch":
         monkeypatch.setenv("FHE_HIP_SPLIT_KEYSWITCH", "1")
+    if forms == "two-launch":           # also where the default keeps the one-launch kernel (lazy 64-bit field, full multiply of the full-range one)
+        monkeypatch.setenv("FHE_HIP_CT_FORM", "two")
     moduli = _moduli(spec, n); L = len(moduli)
     e = eng.RnsNttEngine(n, moduli); rp = oracle.RnsPlan(n, moduli)
     a0, a1, b0, b1 = (rns_poly(s, moduli, n, batch) for s in (71, 72, 73, 74))
