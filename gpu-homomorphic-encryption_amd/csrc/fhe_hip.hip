@@ -684,16 +684,18 @@ static int big_inverse(fhe_rns_ntt *h, void *data, uint32_t polys) {
     return lds_big(h, fhe_dev::LDS_PASS_INV, data, data, nullptr, polys, false, "word_pass_kernel");
 }
 
-// Key switch / external product of the 8-byte residues: ONE workgroup per (ciphertext, limb) with three live arrays
-// (ntt_keyswitch3_kernel / ntt_extprod3_kernel) instead of the split form -- everywhere it was faster in the interleaved A/B
-// (scripts/ab_keyswitch3.sh, ab_extprod3.sh, ab_joint3_small.sh): N >= 2^12 for the integer fields (+13...+50 %; at N = 2048 the split
-// forms are 3-17 % ahead), N >= 2^13 for the key switch of the FP64 field (at N = 4096 its split form is 0-20 % ahead: 128-thread
-// workgroups, enough of them per CU), every size for the external product of the FP64 field (+17...+46 %).
-static bool use_joint3(const fhe_rns_ntt *h, bool extprod) {
+// Key switch / external product of the 8-byte residues (and of the 4-byte residues at N = 2^15): ONE workgroup per (ciphertext, limb)
+// with three live arrays (ntt_keyswitch3_kernel / ntt_extprod3_kernel) instead of the split form -- everywhere it was faster in the
+// interleaved A/B (scripts/ab_keyswitch3.sh, ab_extprod3.sh, ab_joint3_small.sh; with the descriptor loads of round 2): every size for
+// the lazy 64-bit field (+4...+60 %) and for the FP64 field's external product and compact-operand key switch (+10...+46 %); the FP64
+// field's stand-alone key switch (container operands) from N = 2^13 (3-6 % behind at N <= 4096); the full-range 64-bit field from
+// N = 2^12 (at N = 2048: key switch -3 %, external product -16 %).
+static bool use_joint3(const fhe_rns_ntt *h, bool extprod, bool compact) {
     const int eb = h->width == FHE_WIDTH_32 ? 4 : 8;
     if (h->split_keyswitch || !fhe_dev::lds_keyswitch_joint3(eb, (int)h->log_n)) return false;
-    if (h->width == FHE_WIDTH_52) return extprod || h->log_n >= 13;
-    return h->log_n >= 12;   // (4-byte residues reach here only at N = 2^15)
+    if (h->width == FHE_WIDTH_52) return extprod || compact || h->log_n >= 13;
+    if (h->width == FHE_WIDTH_64X) return h->log_n >= 12;
+    return true;
 }
 // Tensor product in two launches (ntt_forward_compact_kernel + ntt_ct_a_kernel, workspace for the transformed b-side) instead of the
 // one-launch kernel: always where that kernel does not exist (8-byte residues at N = 2^14, N = 2^15), and for the 8-byte residues
@@ -1124,7 +1126,7 @@ extern "C" int fhe_ct_relinearize(fhe_rns_ntt_t *h, const fhe_relin_keys_t *rk, 
         A.kb = rk->d_pkb; A.ka = rk->d_pka; A.K = rk->K; A.w = rk->decomp_bits;
         A.global_twiddles = h->global_twiddles;
         A.single_transforms = h->single_transforms;
-        A.joint3 = use_joint3(h, false);
+        A.joint3 = use_joint3(h, false, false);
         fn(A);
         return post_launch(h->stream, "ntt_keyswitch_kernel");
     }
@@ -1183,7 +1185,7 @@ extern "C" int fhe_ct_multiply_relin(fhe_rns_ntt_t *h, const fhe_relin_keys_t *r
         if ((rc = post_launch(h->stream, "tensor product (compact outputs)"))) return rc;
         fhe_dev::LdsArgs B{fhe_dev::LDS_KEYSWITCH, d_c0, d_c1, nullptr, c2c, c0c, c1c, nullptr, h->d_limbs, h->L, polys, h->stream};
         B.kb = rk->d_pkb; B.ka = rk->d_pka; B.K = rk->K; B.w = rk->decomp_bits; B.compact_c2 = true;
-        B.joint3 = use_joint3(h, false);
+        B.joint3 = use_joint3(h, false, true);
         fn(B);
         return post_launch(h->stream, "key switch (compact operands)");
     }
@@ -1474,7 +1476,7 @@ static int blind_rotate_step_fused(fhe_rns_ntt_t *h, const fhe_relin_keys_t *r0,
     fhe_dev::LdsArgs A{fhe_dev::LDS_EXTPROD, out0, out1, nullptr, in0, in1, nullptr, nullptr, h->d_limbs, h->L, batch * h->L, h->stream};
     A.kb = r0->d_pkb; A.ka = r0->d_pka; A.kb1 = r1->d_pkb; A.ka1 = r1->d_pka; A.K = r0->K; A.w = r0->decomp_bits; A.shifts = d_shifts;
     A.in_compact = in_compact; A.out_compact = out_compact;
-    A.joint3 = use_joint3(h, true);
+    A.joint3 = use_joint3(h, true, false);
     A.global_twiddles = h->global_twiddles;
     A.single_transforms = h->single_transforms;
     fn(A);
