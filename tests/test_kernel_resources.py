@@ -124,11 +124,14 @@ def test_f52_n16384_instance(resources):
             assert k.get("scratch", 0) == 0 and k["occupancy"] >= 2 and k["lds"] == 135168, (name, k)
     for k in _all(kernels, "ntt_forward_compact_kernel"):           # first launch of the two-launch tensor product
         assert k.get("scratch", 0) == 0 and k["occupancy"] >= 2, k
-    # bytes per lane today: 160 / 216 / 360; ntt_ct_a_kernel 164 (compact outputs) / 644 (container outputs: the compiler parks the
-    # canonical a-side in scratch across the inverse transform + container store, one store and one load per value)
-    # ntt_keyswitch3_kernel 444 / 464 (both accumulators + the digit polynomial: about one accumulator's worth is parked per digit)
-    bounds = {"ntt_mac2_kernel": 200, "ntt_keyswitch_kernel": 260, "ntt_extprod_kernel": 420, "ntt_ct_a_kernel": 700, "ntt_keyswitch3_kernel": 520,
-              "ntt_extprod3_kernel": 720}      # 660 today
+    # second launch: scratch-free with compact outputs since its loads go through buffer descriptors (164 B before); the container-output
+    # form parks part of the canonical a-side across the inverse transform + store (132 B today, 644 B with flat addresses)
+    for k in _all(kernels, "ntt_ct_a_kernelINS_3F52ELi14ELi2ELb1E"):
+        assert k.get("scratch", 0) == 0, k
+    # bytes per lane today: mac2 160 / split key switch 216 / split external product 360; three-array key switch 152-160 (444 with flat
+    # addresses: the compiler hoisted 34 64-bit address pairs out of the digit loops and spilled them), external product 624
+    bounds = {"ntt_mac2_kernel": 200, "ntt_keyswitch_kernel": 260, "ntt_extprod_kernel": 420, "ntt_ct_a_kernel": 200, "ntt_keyswitch3_kernel": 220,
+              "ntt_extprod3_kernel": 720}
     for name, cap in bounds.items():
         for k in _all(kernels, name):
             assert k["vgprs"] <= 256 and k["occupancy"] >= 2 and k.get("scratch", 0) <= cap, (name, k)
