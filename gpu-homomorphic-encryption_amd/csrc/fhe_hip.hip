@@ -1066,7 +1066,10 @@ extern "C" int fhe_relin_keys_create(fhe_rns_ntt_t *h, fhe_relin_keys_t **out, u
         for (const U256 &q : h->moduli) { fhe_host::u128 v = q.w[0]; q_min = v < q_min ? v : q_min; q_max = v > q_max ? v : q_max; }
         digits_fit = (decomp_bits >= 64 ? q_max : (((fhe_host::u128)1 << decomp_bits) < q_max ? ((fhe_host::u128)1 << decomp_bits) : q_max)) <= q_min;
     }
-    if (!rc && h->width != FHE_WIDTH_256 && !h->sub_top && digits_fit && !h->no_fused_keyswitch) {
+    // the fused kernels address a packed table through a buffer descriptor with 32-bit offsets (fhe_dev::TableBuf): a table of 4 GiB or
+    // more (L*K*L*n residues: not reached by any parameter set of the reference) stays on the general composition
+    const bool table_fits = (size_t)rk->num_keys * h->L * h->n * (h->width == FHE_WIDTH_32 ? 4 : 8) < ((size_t)1 << 32);
+    if (!rc && h->width != FHE_WIDTH_256 && !h->sub_top && digits_fit && table_fits && !h->no_fused_keyswitch) {
         rc = pack_relin_keys(h, rk);
         if (!rc) {   // the fused kernels read only the packed tables (n * sizeof(E) bytes per key polynomial instead of n * 32): drop the
                      // container copy, so that a bootstrapping key of several hundred RGSW ciphertexts fits (hipFree waits for the packing)
