@@ -18,7 +18,7 @@
 #include "ntt_wide.hip.h"
 #include "sampling.hip.h"
 #include "lds_launch.h"
-#include "ntt_lds.hip.h"
+#include "ntt_word.hip.h"
 
 using fhe_host::U256;
 

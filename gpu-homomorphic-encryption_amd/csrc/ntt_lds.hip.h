@@ -24,281 +24,10 @@
 //     loads from an L2-resident table shared by the whole batch.
 #pragma once
 #include <hip/hip_runtime.h>
-#include <stdint.h>
 
-#include "u256_dev.h"
+#include "ntt_field.hip.h"
 
 namespace fhe_dev {
-
-typedef uint32_t v4u32 __attribute__((ext_vector_type(4)));   // native vectors: accepted by the nontemporal builtins
-typedef uint64_t v2u64 __attribute__((ext_vector_type(2)));
-
-// ---- field traits ---------------------------------------------------------------------------------------
-// A field supplies the residue type E, the twiddle record TW = (w, companion), the butterflies and the
-// range bookkeeping.  "lazy" ranges: integer fields keep forward values in [0,4q) and inverse values in [0,2q);
-// the floating-point field keeps signed values whose magnitude stays far below 2^53.
-template <class E>
-__device__ __forceinline__ E csub(E x, E c) {   // x - (x >= c ? c : 0) for unsigned E
-    E d = x - c;
-    return d < x ? d : x;                       // sub + unsigned min (d wraps above x exactly when x < c)
-}
-
-template <class Self, class E_, class TW_>
-struct IntField {
-    using E = E_;
-    using TW = TW_;
-    // Harvey lazy Cooley-Tukey butterfly, inputs and outputs in [0,4q)
-    template <class L> __device__ static __forceinline__ void fwd_bfly(E &x0, E &x1, const TW &w, const L &P) {
-        E X = csub<E>(x0, P.q2);
-        E T = Self::tw_mul(x1, w, P);
-        x0 = X + T;
-        x1 = X - T + P.q2;
-    }
-    // Harvey lazy Gentleman-Sande butterfly, inputs and outputs in [0,2q)
-    template <class L> __device__ static __forceinline__ void inv_bfly(E &x0, E &x1, const TW &w, const L &P) {
-        E X = x0, Y = x1;
-        x0 = csub<E>(X + Y, P.q2);
-        x1 = Self::tw_mul(X - Y + P.q2, w, P);
-    }
-    // x * twiddle mod q, result in [0, 2q): Shoup form (w, floor(w*2^W/q)) unless the field overrides it
-    template <class L> __device__ static __forceinline__ E tw_mul(E x, const TW &w, const L &P) { return Self::shoup_mul(x, w.x, w.y, P.q); }
-    // last inverse stage with the n^-1 scaling folded in (outputs in [0,2q))
-    __device__ static __forceinline__ void inv_last(E &x0, E &x1, E q, E q2, E ninv, E ninv_s, E ninvw, E ninvw_s) {
-        E X = x0, Y = x1;
-        x0 = Self::shoup_mul(X + Y, ninv, ninv_s, q);
-        x1 = Self::shoup_mul(X - Y + q2, ninvw, ninvw_s, q);
-    }
-    __device__ static __forceinline__ void regroup(E (&)[32], E, E) {}                       // integer ranges never grow
-    __device__ static __forceinline__ E regroup1(E x, E, E) { return x; }
-    __device__ static __forceinline__ E canon_fwd(E x, E q, E q2, E) { return csub<E>(csub<E>(x, q2), q); }   // [0,4q) -> [0,q)
-    __device__ static __forceinline__ E canon_inv(E x, E q) { return csub<E>(x, q); }       // [0,2q) -> [0,q)
-    // NTT-domain product for the fused kernels: a canonical, b lazy (< 4q); result in [0,2q), carries 2^-W
-    __device__ static __forceinline__ E pw_mul(E a, E b, E q, E qinv) { return Self::mont_mul(a, b, q, qinv); }
-    // a0*b0 + a1*b1 in the NTT domain (a* canonical, b* lazy), result in [0,2q), carries 2^-W; F32 overrides it with one shared reduction
-    __device__ static __forceinline__ E pw_mul2(E a0, E b0, E a1, E b1, E q, E q2, E qinv) {
-        return csub<E>(Self::mont_mul(a0, b0, q, qinv) + Self::mont_mul(a1, b1, q, qinv), q2);
-    }
-    // [0,2q)+[0,2q) -> [0,2q)
-    __device__ static __forceinline__ E pw_add(E a, E b, E, E q2) { return csub<E>(a + b, q2); }
-    // element-wise canonical ops
-    template <class L> __device__ static __forceinline__ E ew_mul(E x, E y, const L &P) {
-        return csub<E>(Self::shoup_mul(Self::mont_mul(x, y, P.q, P.qinv), P.r1, P.r1_s, P.q), P.q);
-    }
-    __device__ static __forceinline__ E ew_add(E x, E y, E q) { return csub<E>(x + y, q); }
-    __device__ static __forceinline__ E ew_sub(E x, E y, E q) { return csub<E>(x - y + q, q); }
-    __device__ static __forceinline__ bool ge(uint64_t raw, E q) { return raw >= (uint64_t)q; }
-    __device__ static __forceinline__ E from_u64(uint64_t d, E q) { return (E)(d % (uint64_t)q); }   // canonical residue of a small integer
-    // bits [lo, lo+w) of a residue (lo < bit width of E)
-    __device__ static __forceinline__ E digit(E x, uint32_t lo, uint32_t w) {
-        E v = x >> lo;
-        return w >= 8 * sizeof(E) ? v : (E)(v & (((E)1 << w) - 1));
-    }
-    // canonical x -> the operand form pw_mul expects on its canonical side so that the product comes out plain: x * 2^W mod q
-    template <class L> __device__ static __forceinline__ E to_pw_operand(E x, const L &P) { return csub<E>(Self::shoup_mul(x, P.r1, P.r1_s, P.q), P.q); }
-};
-
-template <class Self, class TW_>
-struct F32Base : IntField<Self, uint32_t, TW_> {
-    using E = uint32_t;
-    using V16 = v4u32;                  // one 16-byte half container
-    static constexpr int MAX_LOGN = 15;
-    static constexpr int MULT_MINW = 4; // waves per SIMD the fused multiply is compiled for (4 workgroups per CU at N = 8192)
-    // x*w mod q for w < q with companion ws = floor(w*2^32/q); any x; result in [0, 2q).
-    __device__ static __forceinline__ E shoup_mul(E x, E w, E ws, E q) { return x * w - __umulhi(x, ws) * q; }
-    // a*b*2^-32 mod q for a*b < q*2^32; result in [0, 2q).  nqinv = -q^-1 mod 2^32 (Limb::qinv holds the NEGATED inverse on this
-    // field): m = t * nqinv makes t + m*q divisible by 2^32, and the whole reduction is ONE v_mad_u64_u32 (multiply + 64-bit add)
-    // instead of v_mul_hi + v_sub + v_add: 3 multiply-class instructions per product and no additions.  t + m*q < 2 q 2^32 < 2^63.
-    __device__ static __forceinline__ E mont_mul(E a, E b, E q, E nqinv) {
-        const uint64_t t = (uint64_t)a * b;
-        const E m = (E)t * nqinv;
-        return (E)(((uint64_t)m * q + t) >> 32);
-    }
-    // (a0*b0 + a1*b1) * 2^-32 mod q with ONE reduction: the second product rides on the first as the addend of its
-    // v_mad_u64_u32.  a0, a1 < q (key entries), b0, b1 < 4q (lazy transform outputs), q < 2^30: the sum is < 8q^2 < 2^63 and
-    // the result < 8q^2 / 2^32 + q < 3q; one conditional subtraction brings it to [0, 2q).  4 multiply-class instructions
-    // for two products instead of 6, and one accumulation instead of two.
-    __device__ static __forceinline__ E mont_mul2(E a0, E b0, E a1, E b1, E q, E q2, E nqinv) {
-        const uint64_t t = (uint64_t)a1 * b1 + (uint64_t)a0 * b0;
-        const E m = (E)t * nqinv;
-        return csub<E>((E)(((uint64_t)m * q + t) >> 32), q2);
-    }
-    __device__ static __forceinline__ E pw_mul2(E a0, E b0, E a1, E b1, E q, E q2, E nqinv) { return mont_mul2(a0, b0, a1, b1, q, q2, nqinv); }
-    __device__ static __forceinline__ E load_low(const void *container) { return __builtin_nontemporal_load((const E *)container); }
-    __device__ static __forceinline__ V16 pack(E v) { V16 o = {v, 0u, 0u, 0u}; return o; }
-    __device__ static __forceinline__ uint64_t low(const V16 &v) { return v.x; }
-    __device__ static __forceinline__ bool upper_nonzero(const V16 &v) { return (v.y | v.z | v.w) != 0; }
-    __device__ static __forceinline__ bool any_nonzero(const V16 &v) { return (v.x | v.y | v.z | v.w) != 0; }
-};
-// 32-bit field: twiddles in Montgomery form w*2^32 mod q -- 4 multiply-class instructions per butterfly instead
-// of Shoup's 3, but 4 instead of 8 bytes per twiddle (registers, L2 traffic, vector-memory issue slots).  Interleaved A/B
-// against Shoup-form twiddles on one MI355X (scratch/kbench.hip, batch 4096): 6.10 vs 6.02 TB/s on the fused multiply,
-// bit-identical results.
-struct F32 : F32Base<F32, uint32_t> {
-    template <class L> __device__ static __forceinline__ E tw_mul(E x, const uint32_t &w, const L &P) { return mont_mul(x, w, P.q, P.qinv); }
-};
-struct F64 : IntField<F64, uint64_t, ulonglong2> {
-    using V16 = v2u64;
-    static constexpr int MAX_LOGN = 14; // 2^15 x 8 B does not fit the 160 KiB LDS
-    static constexpr int MULT_MINW = 2;
-    __device__ static __forceinline__ E shoup_mul(E x, E w, E ws, E q) { return x * w - __umul64hi(x, ws) * q; }
-    __device__ static __forceinline__ E mont_mul(E a, E b, E q, E qinv) {
-        E lo = a * b, hi = __umul64hi(a, b);
-        E m = lo * qinv;
-        return hi - __umul64hi(m, q) + q;
-    }
-    __device__ static __forceinline__ E load_low(const void *container) { return __builtin_nontemporal_load((const E *)container); }
-    __device__ static __forceinline__ V16 pack(E v) { V16 o = {v, 0ull}; return o; }
-    __device__ static __forceinline__ uint64_t low(const V16 &v) { return v.x; }
-    __device__ static __forceinline__ bool upper_nonzero(const V16 &v) { return v.y != 0; }
-    __device__ static __forceinline__ bool any_nonzero(const V16 &v) { return (v.x | v.y) != 0; }
-};
-
-// Full-range 64-bit field: ANY odd prime q < 2^64 (in practice 2^62 <= q < 2^64, the primes the lazy F64 ranges cannot hold: its
-// [0, 4q) / [0, 2q) bookkeeping needs 4q < 2^64).  Values stay canonical in [0, q) through every butterfly; sums and differences go
-// through the carry / borrow (addm / subm), products are canonical Montgomery products hi(a*b) - hi(m*q) (+ q on borrow), so
-// twiddles are single words w * 2^64 mod q (8 bytes instead of F64's 16-byte Shoup pairs).  Limb<F64X> holds: qinv = q^-1 mod 2^64,
-// r1 = 2^128 mod q, ninv / ninvw = n^-1 (* itw[1]) * 2^64, ninv_r / ninvw_r = the same * 2^128; every *_s slot holds qinv again
-// (inv_last receives no qinv of its own, and there are no Shoup companions on this field).
-struct F64X : IntField<F64X, uint64_t, uint64_t> {
-    using V16 = v2u64;
-    static constexpr int MAX_LOGN = 14;
-    static constexpr int MULT_MINW = 2;
-    __device__ static __forceinline__ E addm(E a, E b, E q) { E s = a + b; return (s < a || s >= q) ? s - q : s; }
-    __device__ static __forceinline__ E subm(E a, E b, E q) { E d = a - b; return a < b ? d + q : d; }
-    // a*b*2^-64 mod q, canonical, for a*b < q*2^64 (one factor below q, the other any 64-bit word)
-    __device__ static __forceinline__ E mont_mul(E a, E b, E q, E qinv) {
-        const E lo = a * b, hi = __umul64hi(a, b);
-        const E mh = __umul64hi(lo * qinv, q);
-        const E d = hi - mh;
-        return hi < mh ? d + q : d;
-    }
-    template <class L> __device__ static __forceinline__ E tw_mul(E x, const TW &w, const L &P) { return mont_mul(x, w, P.q, P.qinv); }
-    template <class L> __device__ static __forceinline__ void fwd_bfly(E &x0, E &x1, const TW &w, const L &P) {
-        const E T = mont_mul(x1, w, P.q, P.qinv), X = x0;
-        x0 = addm(X, T, P.q);
-        x1 = subm(X, T, P.q);
-    }
-    template <class L> __device__ static __forceinline__ void inv_bfly(E &x0, E &x1, const TW &w, const L &P) {
-        const E X = x0, Y = x1;
-        x0 = addm(X, Y, P.q);
-        x1 = mont_mul(subm(X, Y, P.q), w, P.q, P.qinv);
-    }
-    __device__ static __forceinline__ void inv_last(E &x0, E &x1, E q, E, E ninv, E qinv, E ninvw, E) {
-        const E X = x0, Y = x1;
-        x0 = mont_mul(addm(X, Y, q), ninv, q, qinv);
-        x1 = mont_mul(subm(X, Y, q), ninvw, q, qinv);
-    }
-    __device__ static __forceinline__ E canon_fwd(E x, E, E, E) { return x; }
-    __device__ static __forceinline__ E canon_inv(E x, E) { return x; }
-    __device__ static __forceinline__ E pw_mul(E a, E b, E q, E qinv) { return mont_mul(a, b, q, qinv); }
-    __device__ static __forceinline__ E pw_mul2(E a0, E b0, E a1, E b1, E q, E, E qinv) { return addm(mont_mul(a0, b0, q, qinv), mont_mul(a1, b1, q, qinv), q); }
-    __device__ static __forceinline__ E pw_add(E a, E b, E q, E) { return addm(a, b, q); }
-    template <class L> __device__ static __forceinline__ E ew_mul(E x, E y, const L &P) { return mont_mul(mont_mul(x, y, P.q, P.qinv), P.r1, P.q, P.qinv); }
-    __device__ static __forceinline__ E ew_add(E x, E y, E q) { return addm(x, y, q); }
-    __device__ static __forceinline__ E ew_sub(E x, E y, E q) { return subm(x, y, q); }
-    template <class L> __device__ static __forceinline__ E to_pw_operand(E x, const L &P) { return mont_mul(x, P.r1, P.q, P.qinv); }
-    __device__ static __forceinline__ E load_low(const void *container) { return __builtin_nontemporal_load((const E *)container); }
-    __device__ static __forceinline__ V16 pack(E v) { V16 o = {v, 0ull}; return o; }
-    __device__ static __forceinline__ uint64_t low(const V16 &v) { return v.x; }
-    __device__ static __forceinline__ bool upper_nonzero(const V16 &v) { return v.y != 0; }
-    __device__ static __forceinline__ bool any_nonzero(const V16 &v) { return (v.x | v.y) != 0; }
-};
-
-// Residues as exact integers in IEEE doubles (q < 2^43).  x*w mod q with the precomputed companion wq = fl(w/q):
-//   h = fl(x*w), l = x*w - h (exact, one FMA), c = rint(fl(x*wq)), d = h - c*q (exact, one FMA), r = d + l.
-// For |x| < 2^49: |fl(x*wq) - x*w/q| < 2^-2, so c is within 1 of the nearest integer and |r| < 0.76 q; h - c*q and l are
-// integers below 2^53 in magnitude, hence every step is exact and r == x*w (mod q).  Six half-rate FP64 instructions
-// replace the ~20 half-rate 32-bit integer multiplies of a 64-bit Shoup product (measured 4.5 vs 63+ cycles per wave).
-// Butterfly outputs are not range-reduced: forward values grow by < 0.76 q per stage (<= 12 q after 14 stages), inverse
-// values are brought back below 0.76 q once per 5-stage register group (regroup).
-struct F52 {
-    using E = double;
-    using TW = double;                  // w only: the companion fl(w / q) is recomputed as fl(w * fl(1/q)) (one FP64 multiply
-                                        // instead of 2 more VGPRs and 8 more L2 bytes per twiddle; |error| of c stays < 0.15)
-    using V16 = v2u64;
-    static constexpr int MAX_LOGN = 14;
-    static constexpr int MULT_MINW = 2;
-    __device__ static __forceinline__ E mulmod(E x, E w, E wq, E q) {
-#pragma clang fp contract(off)
-        E h = x * w;
-        E l = __builtin_fma(x, w, -h);
-        E c = __builtin_rint(x * wq);
-        E d = __builtin_fma(-c, q, h);
-        return d + l;
-    }
-    __device__ static __forceinline__ E reduce(E x, E q, E qinv) {       // |x| < 2^49 -> |r| < 0.76 q
-#pragma clang fp contract(off)
-        E c = __builtin_rint(x * qinv);
-        return __builtin_fma(-c, q, x);
-    }
-    template <class L> __device__ static __forceinline__ void fwd_bfly(E &x0, E &x1, const TW &w, const L &P) {
-#pragma clang fp contract(off)
-        E T = mulmod(x1, w, w * P.qinv, P.q);
-        x1 = x0 - T;
-        x0 = x0 + T;
-    }
-    template <class L> __device__ static __forceinline__ void inv_bfly(E &x0, E &x1, const TW &w, const L &P) {
-#pragma clang fp contract(off)
-        E S = x0 + x1, D = x0 - x1;
-        x0 = S;
-        x1 = mulmod(D, w, w * P.qinv, P.q);
-    }
-    __device__ static __forceinline__ void inv_last(E &x0, E &x1, E q, E, E ninv, E ninv_s, E ninvw, E ninvw_s) {
-        E S = x0 + x1, D = x0 - x1;
-        x0 = mulmod(S, ninv, ninv_s, q);
-        x1 = mulmod(D, ninvw, ninvw_s, q);
-    }
-    __device__ static __forceinline__ void regroup(E (&x)[32], E q, E qinv) {
-#pragma unroll
-        for (int r = 0; r < 32; r++) x[r] = reduce(x[r], q, qinv);
-    }
-    __device__ static __forceinline__ E regroup1(E x, E q, E qinv) { return reduce(x, q, qinv); }
-    __device__ static __forceinline__ E canon_fwd(E x, E q, E, E qinv) { E r = reduce(x, q, qinv); return r < 0 ? r + q : r; }
-    __device__ static __forceinline__ E canon_inv(E x, E q) { return x < 0 ? x + q : x; }   // |x| < 0.76 q
-    __device__ static __forceinline__ E pw_mul(E a, E b, E q, E qinv) {                     // a in [0,q), |b| < 2^48
-#pragma clang fp contract(off)
-        E h = a * b;
-        E l = __builtin_fma(a, b, -h);
-        E c = __builtin_rint(h * qinv);
-        E d = __builtin_fma(-c, q, h);
-        return d + l;
-    }
-    __device__ static __forceinline__ E pw_add(E a, E b, E, E) { return a + b; }
-    __device__ static __forceinline__ E pw_mul2(E a0, E b0, E a1, E b1, E q, E, E qinv) { return pw_mul(a0, b0, q, qinv) + pw_mul(a1, b1, q, qinv); }
-    template <class L> __device__ static __forceinline__ E ew_mul(E x, E y, const L &P) { return canon_inv(pw_mul(x, y, P.q, P.qinv), P.q); }
-    __device__ static __forceinline__ E ew_add(E x, E y, E q) { E t = x + y; return t >= q ? t - q : t; }
-    __device__ static __forceinline__ E ew_sub(E x, E y, E q) { E t = x - y; return t < 0 ? t + q : t; }
-    __device__ static __forceinline__ E load_low(const void *container) { return (E)__builtin_nontemporal_load((const uint64_t *)container); }
-    __device__ static __forceinline__ V16 pack(E v) { V16 o = {(uint64_t)v, 0ull}; return o; }
-    __device__ static __forceinline__ uint64_t low(const V16 &v) { return v.x; }
-    __device__ static __forceinline__ bool upper_nonzero(const V16 &v) { return v.y != 0; }
-    __device__ static __forceinline__ bool any_nonzero(const V16 &v) { return (v.x | v.y) != 0; }
-    __device__ static __forceinline__ bool ge(uint64_t raw, E q) { return (E)raw >= q; }
-    __device__ static __forceinline__ E from_u64(uint64_t d, E q) { return (E)(d % (uint64_t)q); }
-    __device__ static __forceinline__ E digit(E x, uint32_t lo, uint32_t w) {
-        uint64_t v = (uint64_t)x >> lo;
-        return (E)(w >= 64 ? v : (v & ((1ull << w) - 1)));
-    }
-    template <class L> __device__ static __forceinline__ E to_pw_operand(E x, const L &) { return x; }
-};
-
-// Per-limb constants (device memory, one entry per RNS prime).  *_s = Shoup companion floor(x*2^W/q).
-template <class F>
-struct Limb {
-    using E = typename F::E;
-    E q, q2, qinv, _pad0;                 // qinv = q^-1 mod 2^W   (F32: -q^-1 mod 2^32; F52: fl(1/q))
-    E r1, r1_s;                           // 2^W mod q             (undo the 2^-W of mont_mul in `pointwise`)
-    E ninv, ninv_s;                       // n^-1
-    E ninvw, ninvw_s;                     // n^-1 * itw[1]
-    E ninv_r, ninv_r_s;                   // n^-1 * 2^W            (fused multiply: absorbs mont_mul's 2^-W)
-    E ninvw_r, ninvw_r_s;                 // n^-1 * itw[1] * 2^W
-    const typename F::TW *tw;             // [n] (psi^bitrev(k), shoup)
-    const typename F::TW *itw;            // [n] (psi^-bitrev(k), shoup)
-};
-using Limb32 = Limb<F32>;
-using Limb64 = Limb<F64>;
-using Limb64X = Limb<F64X>;
-using Limb52 = Limb<F52>;
 
 template <int LOGN>
 struct NttCfg {
@@ -486,29 +215,6 @@ __device__ __forceinline__ void load_src(const char *__restrict__ base, size_t p
     else load_A<F, LOGN>(base + poly_index * (NttCfg<LOGN>::N * 32), tid, x);
 }
 
-// 16-byte loads of table rows through a buffer descriptor: SGPR base + ONE shared VGPR offset (tid * 16) + a scalar offset per load
-// (`buffer_load_dwordx4 v, voff, s[rsrc], soff offen`).  With flat pointers every chunk of a key row needs its own 64-bit VGPR address
-// (the chunk stride exceeds the 12-bit immediate), the compiler hoists those out of the digit loops and, in the register-starved
-// kernels, spills them: 34 address pairs in the three-array key switch.  Offsets are 32-bit: the host keeps packed tables below 4 GiB.
-struct TableBuf {
-    __amdgpu_buffer_rsrc_t r;
-    __device__ __forceinline__ explicit TableBuf(const void *base) : r(__builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, 0xffffffffu, 0x00020000)) {}
-    template <class VecE> __device__ __forceinline__ VecE load16(uint32_t voff, uint32_t soff) const {
-        static_assert(sizeof(VecE) == 16, "one 16-byte lane load");
-        return __builtin_bit_cast(VecE, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
-    }
-    // one residue: the low word(s) of a container (an integer, as F::load_low reads it) or a compact slot (the field's own type)
-    template <class F, bool COMPACT> __device__ __forceinline__ typename F::E load_residue(uint32_t voff, uint32_t soff) const {
-        using E = typename F::E;
-        constexpr int AUX = 0;                   // temporal: these loads serve operands that several workgroups re-read (measured: nt costs 2-7 % on relinearisation)
-        if constexpr (sizeof(E) == 4) return __builtin_bit_cast(uint32_t, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, AUX));
-        else {
-            const uint64_t raw = __builtin_bit_cast(uint64_t, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, AUX));
-            if constexpr (COMPACT) return __builtin_bit_cast(E, raw);
-            else return (E)raw;
-        }
-    }
-};
 // load_src through a descriptor based at the first limb polynomial of a ciphertext component (`poly` = limb index within it): the 32
 // loads of a thread share one VGPR offset, the per-load strides are scalar
 template <class F, int LOGN, bool COMPACT>
@@ -523,18 +229,6 @@ __device__ __forceinline__ void load_src_buf(const TableBuf &B, uint32_t poly, u
 template <class F, int LOGN, bool COMPACT>
 __device__ __forceinline__ void load_poly_buf(const void *poly, uint32_t tid, typename F::E (&x)[32]) {
     load_src_buf<F, LOGN, COMPACT>(TableBuf(poly), 0, tid, x);
-}
-
-// Every lane of a wave holds the residue `o` of one of 64 consecutive containers starting at half-container `dst`: lane pairs store
-// the value half and the zero half of each container (two instructions of 1 KiB consecutive bytes per wave), so the arithmetic that
-// produced `o` runs on all 64 lanes instead of on the even ones of a one-half-container-per-lane kernel.
-template <class F>
-__device__ __forceinline__ void store_wave_containers(typename F::V16 *dst, typename F::E o) {
-    using E = typename F::E;
-    const uint32_t lane = threadIdx.x & 63;
-    const E lo = __shfl(o, (int)(lane >> 1), 64), hi = __shfl(o, (int)(32 + (lane >> 1)), 64);
-    __builtin_nontemporal_store(F::pack((lane & 1) ? (E)0 : lo), dst + lane);
-    __builtin_nontemporal_store(F::pack((lane & 1) ? (E)0 : hi), dst + 64 + lane);
 }
 
 // Store the whole polynomial from LDS as full containers: consecutive lanes write consecutive 16-byte
@@ -1113,65 +807,7 @@ ntt_ct_multiply_kernel(char *__restrict__ c0, char *__restrict__ c1, char *__res
     }
 }
 
-// Element-wise kernels over [batch][L][n] containers of word-sized residues: one 16-byte half-container per lane.
-// op 0: r = a*b mod q (plain product in the NTT domain); 1: a+b; 2: a-b.
-template <class F, int OP>
-__global__ void __launch_bounds__(256)
-ew_kernel(typename F::V16 *r, const typename F::V16 *a, const typename F::V16 *b,      // no __restrict__: r may be a or b (in-place add / sub / product)
-          const Limb<F> *__restrict__ limbs, uint32_t L, uint32_t log_n, size_t halves) {
-    using E = typename F::E;
-    size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < halves; g += stride) {
-        E o = 0;
-        if (!(g & 1)) {
-            const Limb<F> &P = limbs[(uint32_t)((g >> (log_n + 1)) % L)];
-            E x = F::load_low(a + g), y = F::load_low(b + g), q = P.q;
-            if (OP == 0) o = F::ew_mul(x, y, P);
-            else if (OP == 1) o = F::ew_add(x, y, q);
-            else o = F::ew_sub(x, y, q);
-        }
-        __builtin_nontemporal_store(F::pack(o), r + g);
-    }
-}
-
-// Canonical-input scan: flags any container whose value is >= q or whose upper words are not zero.
-template <class F>
-__global__ void __launch_bounds__(256)
-check_kernel(const typename F::V16 *__restrict__ a, const Limb<F> *__restrict__ limbs, uint32_t L, uint32_t log_n,
-             size_t halves, uint32_t *__restrict__ flag) {
-    size_t stride = (size_t)gridDim.x * blockDim.x;
-    bool bad = false;
-    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < halves; g += stride) {
-        typename F::V16 v = a[g];
-        if (g & 1) bad |= F::any_nonzero(v);
-        else bad |= F::upper_nonzero(v) || F::ge(F::low(v), limbs[(uint32_t)((g >> (log_n + 1)) % L)].q);
-    }
-    if (bad) atomicOr(flag, 1u);
-}
-
-// ---- fused key switching (relinearisation) -----------------------------------------------------------------------------
-// Key tables in the kernel's own register order ("packed"): for level jk and limb i, element (chunk c, thread tid, e) holds
-// KEY_ntt[i][tid*32 + c*VPL + e] * 2^W mod q_i, VPL = 16 / sizeof(E) values per 16-byte lane load, so a wave instruction
-// reads 1 KiB contiguous and pw_mul's 2^-W cancels.  Tables for one engine total 2 * L*K * L * N * sizeof(E) bytes
-// (2 MiB at N = 8192, L = 4, K = 2, F32) and stay L2-resident across the batch.
-template <class F>
-__global__ void __launch_bounds__(256)
-pack_keys_kernel(typename F::E *__restrict__ packed, const typename F::V16 *__restrict__ keys_ntt, const Limb<F> *__restrict__ limbs,
-                 uint32_t L, uint32_t log_n, uint32_t num_keys) {
-    using E = typename F::E;
-    constexpr uint32_t VPL = 16 / sizeof(E);
-    const uint32_t n = 1u << log_n, T = n >> 5;
-    const size_t total = (size_t)num_keys * L * n, stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += stride) {
-        const uint32_t x = (uint32_t)(g & (n - 1));                  // NTT-domain index = tid*32 + r
-        const size_t poly = g >> log_n;                              // jk * L + i
-        const Limb<F> &P = limbs[(uint32_t)(poly % L)];
-        const uint32_t tid = x >> 5, r = x & 31, c = r / VPL, e = r % VPL;
-        E v = F::load_low(keys_ntt + g * 2);
-        packed[poly * n + ((size_t)c * T + tid) * VPL + e] = F::to_pw_operand(v, P);
-    }
-}
-
+// ---- fused key switching (relinearisation): packed key tables are built by pack_keys_kernel (ntt_word.hip.h) --------------------
 // One workgroup per (ciphertext b, limb i): for every limb j of c2 and every digit k, the digit polynomial is formed in
 // registers, transformed under q_i, multiplied with both key halves and accumulated in the NTT domain; two inverse
 // transforms and the additions to c0, c1 finish the job.  HBM traffic per ciphertext: L reads of c2 + read/write of c0, c1
@@ -1747,216 +1383,6 @@ ntt_extprod2_kernel(char *__restrict__ out0, char *__restrict__ out1, const char
                      ((size_t)jk1 * L + i) * C::N, tid, C::T, P);
     }
     finish_pair<F, LOGN, IN_COMPACT, OUT_COMPACT>(acc0, acc1, d0, d1, lds, lds + C::LDS_ELEMS, tid, P, in0, in1, p, out0, out1);
-}
-
-// ---- relinearisation building blocks (general path; the fused key-switch kernels are above) --------------------
-// Digit polynomials of c2 embedded in every limb: D[jk][b][i][x] = ((c2[b][j][x] >> (k*w)) & (2^w - 1)) mod q_i,
-// jk = j*K + k.  One 16-byte half container per lane.
-template <class F>
-__global__ void __launch_bounds__(256)
-digit_embed_kernel(typename F::V16 *__restrict__ D, const typename F::V16 *__restrict__ c2, const Limb<F> *__restrict__ limbs,
-                   uint32_t L, uint32_t log_n, uint32_t K, uint32_t w, uint32_t batch) {
-    using E = typename F::E;
-    const size_t per_poly = (size_t)2 << log_n, per_ct = per_poly * L, per_digit = per_ct * batch, total = per_digit * L * K;
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += stride) {
-        E o = 0;
-        if (!(g & 1)) {
-            const uint32_t jk = (uint32_t)(g / per_digit); const size_t rem = g - (size_t)jk * per_digit;
-            const uint32_t b = (uint32_t)(rem / per_ct); const size_t r2 = rem - (size_t)b * per_ct;
-            const uint32_t i = (uint32_t)(r2 >> (log_n + 1)); const size_t x2 = r2 & (per_poly - 1);
-            const uint32_t j = jk / K, k = jk % K;
-            const uint64_t v = F::low(c2[((size_t)b * L + j) * per_poly + x2]);
-            const uint32_t sh = k * w;
-            uint64_t d = sh >= 64 ? 0 : (v >> sh);
-            if (w < 64) d &= (1ull << w) - 1;
-            o = F::from_u64(d, limbs[i].q);
-        }
-        __builtin_nontemporal_store(F::pack(o), D + g);
-    }
-}
-// acc0[b][i][x] = sum_jk D[jk][b][i][x] * KB[jk][i][x],  acc1 likewise with KA  (all NTT-domain, canonical)
-template <class F>
-__global__ void __launch_bounds__(256)
-relin_mac_kernel(typename F::V16 *__restrict__ acc0, typename F::V16 *__restrict__ acc1, const typename F::V16 *__restrict__ D,
-                 const typename F::V16 *__restrict__ KB, const typename F::V16 *__restrict__ KA, const Limb<F> *__restrict__ limbs,
-                 uint32_t L, uint32_t log_n, uint32_t LK, uint32_t batch) {
-    using E = typename F::E;
-    const size_t per_poly = (size_t)2 << log_n, per_ct = per_poly * L, per_digit = per_ct * batch;
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < per_digit; g += stride) {
-        E s0 = 0, s1 = 0;
-        if (!(g & 1)) {
-            const size_t kidx = g % per_ct;
-            const Limb<F> &P = limbs[(uint32_t)(kidx >> (log_n + 1))];
-            for (uint32_t jk = 0; jk < LK; jk++) {
-                const E d = F::load_low(D + (size_t)jk * per_digit + g);
-                s0 = F::ew_add(s0, F::ew_mul(d, F::load_low(KB + (size_t)jk * per_ct + kidx), P), P.q);
-                s1 = F::ew_add(s1, F::ew_mul(d, F::load_low(KA + (size_t)jk * per_ct + kidx), P), P.q);
-            }
-        }
-        __builtin_nontemporal_store(F::pack(s0), acc0 + g);
-        __builtin_nontemporal_store(F::pack(s1), acc1 + g);
-    }
-}
-
-// ---- RNS conversions on word-sized residues (row N2): rounded drop of the last prime, Bajard fast base conversion -----------
-// The container-level kernels in ntt256.hip.h do these through 256-bit Montgomery products for every width class; for word-sized
-// classes the same arithmetic fits the field type and the kernels are streaming kernels.  Constants are "pw operands"
-// (c * 2^W mod q for the integer fields, c for F52) so that canon(pw_mul(constant, x)) is the plain product c * x mod q.
-template <class F>
-__device__ __forceinline__ typename F::E mul_const(typename F::E cop, typename F::E x, const Limb<F> &P) {
-    return F::canon_inv(F::pw_mul(cop, x, P.q, P.qinv), P.q);
-}
-// out[b][l][x] = (in[b][l][x] - [c]_{q_l}) * q_last^-1 mod q_l, c = the CENTRED residue of in[b][L-1][x] modulo q_last
-// (RNSContext::mod_switch_rns, include/rns.cuh:44, declared only).  (x_l - c) * inv = x_l * inv - c * inv with c = +-mag, mag < q_last:
-// a residue of ANOTHER prime of the class is a valid second operand of the constant product as it stands (no division to reduce it).
-// One lane per (b, x): the last limb is loaded once and every remaining limb produced from it, full 32-byte containers stored as two
-// 16-byte halves by the same lane (+22 % at N = 8192 over one lane per output half-container, which re-read the last limb per limb).
-template <class F>
-__global__ void __launch_bounds__(256)
-rescale_word_kernel(typename F::V16 *__restrict__ out, const typename F::V16 *__restrict__ in, const Limb<F> *__restrict__ limbs,
-                            const typename F::E *__restrict__ inv_ops, uint32_t L, uint32_t log_n, size_t count /* batch * n */) {
-    using E = typename F::E;
-    const size_t stride = (size_t)gridDim.x * blockDim.x, n = (size_t)1 << log_n;
-    const E q_last = limbs[L - 1].q, half = (E)(((uint64_t)q_last - 1) >> 1);
-    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < count; g += stride) {
-        const size_t b = g >> log_n, x = g & (n - 1);
-        const E cl = F::load_low(in + (((b * L + (L - 1)) << log_n) + x) * 2);
-        const bool neg = cl > half;
-        const E mag = neg ? q_last - cl : cl;
-        for (uint32_t l = 0; l + 1 < L; l++) {
-            const Limb<F> &P = limbs[l];
-            const E xl = F::load_low(in + (((b * L + l) << log_n) + x) * 2);
-            const E a = mul_const<F>(inv_ops[l], xl, P), m = mul_const<F>(inv_ops[l], mag, P);
-            const E o = neg ? F::ew_add(a, m, P.q) : F::ew_sub(a, m, P.q);
-            typename F::V16 *dst = out + (((b * (L - 1) + l) << log_n) + x) * 2;
-            __builtin_nontemporal_store(F::pack(o), dst);
-            __builtin_nontemporal_store(F::pack((E)0), dst + 1);
-        }
-    }
-}
-
-// out[b][j][x] = sum_i ([x_i * (Q/q_i)^-1]_{q_i} mod p_j) * ((Q/q_i) mod p_j) mod p_j   (RNSContext::base_extend, include/rns.cuh:47-48, declared only).
-// minv_ops[i] is an operand of source limb i, mat_ops[i * Lp + j] an operand of target limb j.  One half container of the output per lane.
-// ALL_LANES: one output container per lane, stored by lane pairs (store_wave_containers): +8..10 % on the 64-bit integer fields, whose
-// constant products are the cost; the 4-byte and FP64 fields are bandwidth-bound either way and keep one half container per lane
-// (measured 5.0 vs 4.4 and 4.7 vs 4.5 TB/s).
-template <class F, bool ALL_LANES>
-__global__ void __launch_bounds__(256)
-base_convert_word_kernel(typename F::V16 *__restrict__ out, const typename F::V16 *__restrict__ in, const Limb<F> *__restrict__ src, uint32_t L,
-                         const Limb<F> *__restrict__ dst, uint32_t Lp, const typename F::E *__restrict__ minv_ops,
-                         const typename F::E *__restrict__ mat_ops, uint32_t log_n, size_t work /* containers if ALL_LANES, else half containers */) {
-    using E = typename F::E;
-    const size_t stride = (size_t)gridDim.x * blockDim.x, n = (size_t)1 << log_n;
-    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < work; g += stride) {   // n is a multiple of 256: whole waves
-        E o = 0;
-        if (ALL_LANES || !(g & 1)) {
-            const size_t c = ALL_LANES ? g : g >> 1, x = c & (n - 1), pl = c >> log_n, b = pl / Lp;
-            const uint32_t j = (uint32_t)(pl % Lp);
-            const Limb<F> &D = dst[j];
-            for (uint32_t i = 0; i < L; i++) {
-                const Limb<F> &S = src[i];
-                const E ti = mul_const<F>(minv_ops[i], F::load_low(in + (((b * L + i) << log_n) + x) * 2), S);
-                o = F::ew_add(o, mul_const<F>(mat_ops[(size_t)i * Lp + j], ti, D), D.q);   // t_i < q_i: a valid operand modulo p_j as it stands
-            }
-        }
-        if constexpr (ALL_LANES) store_wave_containers<F>(out + 2 * (g - (threadIdx.x & 63)), o);
-        else __builtin_nontemporal_store(F::pack(o), out + g);
-    }
-}
-
-// rns[b][l][x] = values[b][x] mod q_l for ANY 256-bit value (RNS_NTTEngine::to_rns, include/ntt.cuh:114-115, declared only): the value is
-// read as 256 / W words of W bits and reduced as sum_k word_k * (2^(W k) mod q_l); pow_ops[l * NW + k] is the pw operand of
-// 2^(W k) mod q_l, and a word needs no reduction of its own (integer fields: operand < q, word < 2^W, product < q 2^W; FP64 field:
-// 32-bit words, far below its 2^48 operand bound).
-template <class F, class WT>     // WT: the word type the value is cut into (uint32_t for F32 and F52, uint64_t for F64)
-__global__ void __launch_bounds__(256)
-to_rns_word_kernel(typename F::V16 *__restrict__ rns, const typename F::V16 *__restrict__ values, const Limb<F> *__restrict__ limbs,
-                   const typename F::E *__restrict__ pow_ops, uint32_t L, uint32_t log_n, size_t out_containers) {
-    using E = typename F::E;
-    constexpr int NW = 32 / sizeof(WT), HW = NW / 2;                   // words per container / per 16-byte half
-    typedef WT VecW __attribute__((ext_vector_type(HW)));
-    const size_t stride = (size_t)gridDim.x * blockDim.x, n = (size_t)1 << log_n;
-    for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < out_containers; c += stride) {   // n is a multiple of 256: whole waves
-        const size_t x = c & (n - 1), pl = c >> log_n, b = pl / L;
-        const uint32_t l = (uint32_t)(pl % L);
-        const Limb<F> &P = limbs[l];
-        const VecW *v = reinterpret_cast<const VecW *>(values + ((b << log_n) + x) * 2);
-        const VecW lo = v[0], hi = v[1];
-        const E *ops = pow_ops + (size_t)l * NW;
-        E o = 0;
-#pragma unroll
-        for (int k = 0; k < HW; k++) {
-            o = F::ew_add(o, mul_const<F>(ops[k], (E)lo[k], P), P.q);
-            o = F::ew_add(o, mul_const<F>(ops[HW + k], (E)hi[k], P), P.q);
-        }
-        store_wave_containers<F>(rns + 2 * (c - (threadIdx.x & 63)), o);
-    }
-}
-
-// values[b][x] = CRT of the L residues, in [0, Q)  (RNS_NTTEngine::from_rns, include/ntt.cuh:116-117, declared only), word-sized
-// classes: sum_l [x_l * (Q/q_l)^-1]_{q_l} * (Q/q_l) is accumulated as word x 256-bit products in a 320-bit register array (the sum is
-// below L * Q) and brought into [0, Q) by at most L - 1 subtractions.  One lane per value; Mi[l] = Q / q_l as a plain integer.
-template <class F>
-__global__ void __launch_bounds__(256)
-from_rns_word_kernel(u256 *__restrict__ values, const typename F::V16 *__restrict__ rns, const Limb<F> *__restrict__ limbs,
-                     const typename F::E *__restrict__ minv_ops, const u256 *__restrict__ Mi, u256 Q, uint32_t L, uint32_t log_n, size_t count) {
-    const size_t stride = (size_t)gridDim.x * blockDim.x, n = (size_t)1 << log_n;
-    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < count; g += stride) {
-        const size_t b = g >> log_n, x = g & (n - 1);
-        uint64_t acc[5] = {0, 0, 0, 0, 0};
-        for (uint32_t l = 0; l < L; l++) {
-            const uint64_t t = (uint64_t)mul_const<F>(minv_ops[l], F::load_low(rns + (((b * L + l) << log_n) + x) * 2), limbs[l]);
-            const u256 M = Mi[l];
-            u128_t c = 0;
-#pragma unroll
-            for (int i = 0; i < 4; i++) { c += (u128_t)t * M.l[i] + acc[i]; acc[i] = (uint64_t)c; c >>= 64; }
-            acc[4] += (uint64_t)c;
-        }
-        for (uint32_t it = 0; it < L; it++) {                          // acc < L * Q
-            bool ge = acc[4] != 0;
-            if (!ge) {
-                ge = true;
-#pragma unroll
-                for (int i = 3; i >= 0; i--) { if (acc[i] != Q.l[i]) { ge = acc[i] > Q.l[i]; break; } }
-            }
-            if (!ge) break;
-            uint64_t borrow = 0;
-#pragma unroll
-            for (int i = 0; i < 4; i++) { u128_t d = (u128_t)acc[i] - Q.l[i] - borrow; acc[i] = (uint64_t)d; borrow = (uint64_t)(d >> 64) & 1; }
-            acc[4] -= borrow;
-        }
-        u256 r; r.l[0] = acc[0]; r.l[1] = acc[1]; r.l[2] = acc[2]; r.l[3] = acc[3];
-        store_u256(values + g, r);
-    }
-}
-
-// ---- blind-rotation building block: out[b][l][x] = ((X^shift[b] - 1) * in[b][l])[x] over Z_q[x]/(x^n + 1), shift in [0, 2n) ----
-// (FHEContext::blind_rotate is only declared in the reference, include/fhe.cuh:139.)  One 16-byte half container per lane;
-// the rotated read is a shifted contiguous run, so it stays coalesced.
-template <class F>
-__global__ void __launch_bounds__(256)
-monomial_mul_sub_kernel(typename F::V16 *__restrict__ out, const typename F::V16 *__restrict__ in, const uint32_t *__restrict__ shifts,
-                        const Limb<F> *__restrict__ limbs, uint32_t L, uint32_t log_n, size_t halves) {
-    using E = typename F::E;
-    const uint32_t n = 1u << log_n;
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < halves; g += stride) {
-        E o = 0;
-        if (!(g & 1)) {
-            const size_t c = g >> 1, poly = c >> log_n;                   // container index, polynomial index b*L + l
-            const uint32_t x = (uint32_t)(c & (n - 1));
-            const uint32_t a = shifts[poly / L] & (2 * n - 1);
-            uint32_t k = (x + 2 * n - a) & (2 * n - 1);
-            const bool neg = k >= n; k &= n - 1;
-            const E q = limbs[(uint32_t)(poly % L)].q;
-            E v = F::load_low(in + ((poly << log_n) + k) * 2);
-            if (neg) v = F::ew_sub((E)0, v, q);
-            o = F::ew_sub(v, F::load_low(in + g), q);
-        }
-        __builtin_nontemporal_store(F::pack(o), out + g);
-    }
 }
 
 }  // namespace fhe_dev

@@ -20,6 +20,33 @@ def shard_range(total, rank, world):
     return start, start + base + (1 if rank < extra else 0)
 
 
+def limb_shard(num_limbs, rank, world):
+    """Limb split (secondary partitioning; reference docs/ARCHITECTURE.md:499-512 "Distribute RNS components across GPUs"):
+    the limbs l = rank (mod world) of EVERY polynomial.  Empty when world > num_limbs leaves this rank nothing.  Valid for the work that
+    never mixes limbs (transforms, pointwise products, the tensor product); relinearisation / key switching / base conversion read every
+    limb to produce each limb and stay on the batch split."""
+    if world < 1 or not (0 <= rank < world) or num_limbs < 0:
+        raise ValueError("bad shard arguments")
+    return list(range(rank, num_limbs, world))
+
+
+def choose_split(batch, num_limbs, world, cross_limb=False):
+    """Which partitioning a job of `batch` polynomials x `num_limbs` limbs takes on `world` GPUs: the batch split whenever
+    every rank gets a polynomial; the limb split for small batches of limb-independent work; otherwise replicas do not help."""
+    if batch >= world:
+        return "batch"
+    if not cross_limb and num_limbs >= world:
+        return "limb"
+    return "batch" if batch > 0 else "none"
+
+
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
 def init_process_group(backend=None):
     """Rendezvous from the torchrun environment (MASTER_ADDR / MASTER_PORT / RANK / WORLD_SIZE)."""
     import torch.distributed as dist
@@ -27,7 +54,7 @@ def init_process_group(backend=None):
     if world == 1 and os.environ.get("FHE_BENCH_FORCE_DIST") != "1":
         return None
     if world == 1:                              # FHE_BENCH_FORCE_DIST=1 without a launcher: a one-rank group on this host
-        for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29577")):
+        for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", str(_free_port()))):
             os.environ.setdefault(k, v)
     if backend is None:
         import torch

@@ -32,6 +32,12 @@ def test_default_workload_line_has_every_contract_field():
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and 0 < r["frac"] < 1
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     assert r["algorithmic_bytes_per_launch"] == 3 * 32 * 8192 * 4 * 128 and "traffic" in r
+    # a committed PMC profile is only ever attached to the workload it was taken on, and then it must be THIS kernel's traffic
+    if r["traffic"] is not None:
+        assert 0.95 <= r["traffic"] / r["algorithmic_bytes_per_launch"] <= 1.5, r
+    sec = r["secondary"]
+    assert sec["bound"] == "valu-int-mul" and 0 < sec["frac"] < 1 and abs(sec["frac"] - sec["achieved"] / sec["peak"]) < 1e-9
+    assert sec["multiply_class_per_butterfly"] == 3 and r["limiter"] == "hbm"
     assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["launch_ms"] * 1e-3) / 1e9) / r["achieved"] < 1e-6
     b = d["cpu_baseline"]
     assert b["kind"] == "port" and b["unit"] == "polymul/s" and b["value"] > 0 and b["cores"] >= 1 and "sample" in b
@@ -41,6 +47,8 @@ def test_default_workload_line_has_every_contract_field():
     assert d["ranks_seen"] == 1 and d["verified"] is True and d["shard_checksums"] == d["oracle_checksums"] and len(d["shard_checksums"]) == 1
     x = {(e["prime_bits"], e["limbs"]): e for e in d["extra_width_classes"]}
     assert set(x) == {(40, 3), (60, 2), (64, 2), (128, 1), (250, 1)} and all("error" not in e and e["polymul_per_s"] > 0 for e in x.values())
+    assert all(e["secondary"]["bound"] == "valu-int-mul" and 0 < e["secondary"]["frac"] < 1.2 for e in x.values())
+    assert x[(250, 1)]["secondary"]["multiply_class_per_butterfly"] == 136 and x[(128, 1)]["secondary"]["multiply_class_per_butterfly"] == 136
     assert x[(250, 1)]["width_class"] == 4 and x[(40, 3)]["width_class"] == 3
 
 
@@ -88,4 +96,24 @@ def test_gpus_n_without_a_device_fails_loudly():
 def test_other_workloads_report_their_own_units(op, unit):
     d = _run("--steps", "2", "--warmup", "1", "--batch", "16", "--op", op, "--no-cpu-baseline")
     assert d["unit"] == unit and d["value"] > 0 and d["config"]["op"] == op and "cpu_baseline" not in d
-    assert d["roofline"]["limiter"] in ("hbm", "valu-int32-multiply")
+    r = d["roofline"]; S = 32 * 8192 * 4
+    assert r["secondary"]["bound"] == "valu-int-mul" and r["secondary"]["frac"] > 0
+    # the fraction credits only the bytes the CALL must move; the accounting of earlier rounds is a side field
+    want = {"ctrelin": 6 * S * 16, "blindrotate": 4 * S * 16, "fwdinv": 4 * S * 16}[op]
+    assert r["algorithmic_bytes_per_launch"] == want and abs(r["frac"] - want / (r["launch_ms"] * 1e-3) / 1e9 / 8000.0) < 1e-9
+    if op == "ctrelin":
+        assert r["legacy_accounting"]["bytes"] == 12 * S * 16 and d["verified"] is True       # sampled ciphertexts == oracle ct_multiply + relinearize
+    if op == "blindrotate":
+        assert r["legacy_accounting"]["bytes"] == 4 * 8 * S * 16
+
+
+@pytest.mark.gpu
+def test_limb_shard_rehearsal_two_ranks_union_is_the_product():
+    """--gpus 2 --shard limb on the one GPU (gloo): rank 0 computes limbs {0, 2}, rank 1 limbs {1, 3} of the same global polynomials on
+    engines built on those prime subsets; each rank's checksum equals the oracle's for ITS limbs, no collective carries payload."""
+    d = _run("--gpus", "2", "--shard", "limb", "--dist-backend", "gloo", "--device-override", "0", "--batch", "64", "--steps", "3", "--warmup", "1")
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["verified"] is True and d["scaling"] == "strong"
+    assert d["shard_checksums"] == d["oracle_checksums"] and d["shard_checksums"][0] != d["shard_checksums"][1]
+    assert d["config"]["parallelism"].startswith("limb-shard x2") and d["config"]["limbs_of_rank0"] == [0, 2]
+    assert abs(d["value"] - 64 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6          # the ranks jointly produce 64 whole products per step
+    assert d["roofline"]["algorithmic_bytes_per_launch"] == 3 * 32 * 8192 * 2 * 64

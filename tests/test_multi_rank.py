@@ -77,3 +77,79 @@ def test_two_rank_gloo_batch_sharding(tmp_path):
         outs.append(out)
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
     assert "RANK0 OK 2" in outs[0]
+
+
+def test_limb_shard_covers_every_limb_once(pkg):
+    sh = importlib.import_module(pkg.__name__ + ".sharding")
+    for L in (1, 3, 4, 6):
+        for world in (1, 2, 3, 4, 8):
+            parts = [sh.limb_shard(L, r, world) for r in range(world)]
+            assert sorted(l for p in parts for l in p) == list(range(L))
+            assert all(all(l % world == r for l in p) for r, p in enumerate(parts))
+    assert sh.limb_shard(4, 5, 8) == []                      # more ranks than limbs: this rank owns nothing (bench.py refuses that)
+    # when each split applies
+    assert sh.choose_split(1024, 6, 8) == "batch" and sh.choose_split(1, 4, 4) == "limb" and sh.choose_split(2, 6, 4) == "limb"
+    assert sh.choose_split(1, 4, 4, cross_limb=True) == "batch" and sh.choose_split(1, 4, 8) == "batch"
+
+
+LIMB_WORKER = textwrap.dedent("""
+    import importlib, os, sys, hashlib
+    sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+    import numpy as np
+    import torch
+    sh = importlib.import_module("gpu-homomorphic-encryption_amd.sharding")
+    from oracle import pyoracle as orc          # stands in for the GPU engine in this CPU rehearsal
+    from workload import rns_poly
+    import ntt_math as nm
+    dist = sh.init_process_group("gloo")
+    rank, world, _ = sh.env_rank_world()
+    n, L, batch = 256, 3, 2                     # batch < world is the case the limb split exists for; 3 limbs over 2 ranks: {{0, 2}}, {{1}}
+    moduli = nm.ntt_primes(30, n, L)
+    a = rns_poly(1, moduli, n, batch); b = rns_poly(2, moduli, n, batch)      # the SAME global operands on every rank
+    mine = sh.limb_shard(L, rank, world)
+    sub = orc.RnsPlan(n, [moduli[l] for l in mine])     # the rank's engine: built on its prime subset only
+    got = sub.polymul(np.ascontiguousarray(a[:, mine]), np.ascontiguousarray(b[:, mine]))
+    ct = sub.ct_multiply(*(np.ascontiguousarray(x[:, mine]) for x in (a, b, b, a)))
+    # no payload collective on the path; the test gathers the limb results only to compare them with the unsharded product
+    full = np.zeros((world, batch, L, n, 4), dtype=np.int64)
+    full[rank][:, mine] = got.view(np.int64)
+    t = torch.from_numpy(full); dist.all_reduce(t)
+    union = t.numpy().sum(axis=0).view(np.uint64)
+    c1 = np.zeros((world, batch, L, n, 4), dtype=np.int64); c1[rank][:, mine] = ct[1].view(np.int64)
+    t1 = torch.from_numpy(c1); dist.all_reduce(t1)
+    if rank == 0:
+        rp = orc.RnsPlan(n, moduli)
+        assert np.array_equal(union, rp.polymul(a, b)), "union of the ranks' limbs != unsharded product"
+        assert np.array_equal(t1.numpy().sum(axis=0).view(np.uint64), rp.ct_multiply(a, b, b, a)[1])
+        print("RANK0 LIMB OK", world, mine)
+    dist.barrier(); dist.destroy_process_group()
+""")
+
+
+def test_two_rank_gloo_limb_sharding(tmp_path):
+    """world-2 gloo: rank r computes limbs {l : l mod 2 = r} of the product on an engine built on that prime subset; the union of the
+    ranks' limbs is bit-identical to the unsharded oracle product (polymul and the c1 term of the tensor product)."""
+    script = tmp_path / "limb_worker.py"
+    script.write_text(LIMB_WORKER.format(root=ROOT))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=300)
+        except subprocess.TimeoutExpired:
+            p.kill(); out, _ = p.communicate()
+        outs.append(out)
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    assert "RANK0 LIMB OK 2 [0, 2]" in outs[0]
+
+
+def test_limb_shard_refuses_cross_limb_ops():
+    """bench.py --shard limb --op ctrelin must refuse before touching a device, and say why (the digit decomposition crosses limbs)."""
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--shard", "limb", "--op", "ctrelin", "--steps", "1", "--warmup", "0", "--batch", "2"],
+                         capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert res.returncode != 0 and "decompose" in res.stderr and "--shard batch" in res.stderr, res.stderr[-2000:]
