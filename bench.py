@@ -40,8 +40,8 @@ INT_MUL_PEAK = SIMDS * 64 * CLOCK_HZ / MUL_ISSUE_CYCLES
 #   u64 (F64): Shoup product = 64x64 low (3 x 32-bit multiplies) + 64x64 high (4 multiplies + carries) + low     -> 13 / 16
 #   u64 full range (F64X): Montgomery product = 64x64 -> 128 (7), low (3), high (4+)                              -> 18 / 18
 #   multi-limb (wide_asm.inc): 2 NW^2 + NW v_mad_u64_u32 for NW = 4 / 8 32-bit words                              -> 36 / 136
-# and the measured VALU cycles per butterfly (all instructions, scratch/ubench.hip): 27 / 36 / 100 / 110 / 400 / 400.
-MULS = {1: (3, 3, 27.0), 3: (9, 6, 36.0), 2: (13, 16, 100.0), 5: (18, 18, 110.0), 4: (136, 136, 400.0)}
+# and, where measured, the VALU issue time of a whole butterfly in 2.4 GHz cycles (all instructions, scratch/ubench.hip): 27 / 36 / 100.
+MULS = {1: (3, 3, 27.0), 3: (9, 6, 36.0), 2: (13, 16, 100.0), 5: (18, 18, None), 4: (136, 136, None)}
 
 
 def int_mul_model(width_class, op, n, L, K, br_steps=1, wide_nl=4):
@@ -76,7 +76,7 @@ def secondary_roof(width_class, op, n, L, K, units_per_s, wide_nl=4):
     return {"bound": "valu-int-mul", "achieved": achieved / 1e9, "peak": INT_MUL_PEAK / 1e9, "unit": "G lane-multiplies/s", "frac": achieved / INT_MUL_PEAK,
             "butterflies_per_s": bflies * units_per_s, "multiply_class_per_butterfly": MULS[width_class][0] if not (width_class == 4 and wide_nl == 2) else 36,
             # all VALU instructions of a butterfly (multiplies + adds + selects), measured cycles per wave-butterfly per SIMD
-            "valu_issue_frac": bflies * units_per_s * cyc / 64 / (SIMDS * CLOCK_HZ),
+            "valu_issue_frac": None if cyc is None else bflies * units_per_s * cyc / 64 / (SIMDS * CLOCK_HZ),
             "model": "multiply-class lane-instructions per unit (transforms x butterflies x per-butterfly count + NTT-domain products) x units/s "
                      "against 1024 SIMDs x 64 lanes x 2.4 GHz / 4.9 cycles (v_mad_u64_u32 issue, scratch/ubench.hip)"}
 

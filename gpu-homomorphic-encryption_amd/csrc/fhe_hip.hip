@@ -250,11 +250,12 @@ struct fhe_rns_ntt {
     int wide_nl = 0;                    // FHE_WIDTH_256: 64-bit limbs per residue in those kernels (2: q < 2^127, 4: q < 2^255)
     bool wide_tiles = true;             // FHE_HIP_NO_WIDE_TILES=1: every stage as a global-memory pass (cross-check / A-B)
     bool no_square = false, single_transforms = false, global_twiddles = false, check_inputs = false, no_fused_keyswitch = false,
-         no_word_conversions = false, no_fused_blind_rotate = false, no_fused_ct_relin = false, no_compact_blind_rotate = false, no_two_launch_ct = false, split_keyswitch = false;
+         no_word_conversions = false, no_fused_blind_rotate = false, no_fused_ct_relin = false, no_compact_blind_rotate = false, no_two_launch_ct = false, split_keyswitch = false, no_c2_compaction = false;
     int ct_form_force = 0;                         // FHE_HIP_CT_FORM: 0 = by field and size, 1 = one-launch tensor product where it exists, 2 = two-launch where it exists   // environment switches, read once at creation
     std::vector<void *> d_tables;
     void *d_ws = nullptr; size_t ws_bytes = 0;
     void *d_ws2 = nullptr; size_t ws2_bytes = 0;   // c2 of the fused multiply + relinearise (compact or containers); separate from d_ws, which the general paths use
+    void *d_ws3 = nullptr; size_t ws3_bytes = 0;   // compact polynomials between the two launches of a two-pass transform (sub_top != 0)
     uint32_t *d_flag = nullptr;
     std::vector<U256> moduli;
     void *d_crt = nullptr;               // CrtLimb[L], built on first use of to_rns / from_rns (owned by d_tables)
@@ -278,6 +279,7 @@ static void destroy_impl(fhe_rns_ntt *h) {
     for (void *p : h->d_tables) (void)hipFree(p);
     if (h->d_ws) (void)hipFree(h->d_ws);
     if (h->d_ws2) (void)hipFree(h->d_ws2);
+    if (h->d_ws3) (void)hipFree(h->d_ws3);
     if (h->d_cdt) (void)hipFree(h->d_cdt);
     if (h->d_flag) (void)hipFree(h->d_flag);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -532,6 +534,7 @@ static int create_impl(fhe_rns_ntt **out, uint32_t n, const uint64_t (*moduli)[4
     h->no_compact_blind_rotate = getenv("FHE_HIP_NO_COMPACT_BLIND_ROTATE") != nullptr;
     h->no_two_launch_ct = getenv("FHE_HIP_NO_TWO_LAUNCH_CT") != nullptr;
     h->split_keyswitch = getenv("FHE_HIP_SPLIT_KEYSWITCH") != nullptr;
+    h->no_c2_compaction = getenv("FHE_HIP_NO_C2_COMPACTION") != nullptr;   // stand-alone relinearisation of the 8-byte fields: c2 read as containers (A/B, cross-check)
     if (const char *m = getenv("FHE_HIP_CT_FORM")) h->ct_form_force = !strcmp(m, "two") ? 2 : !strcmp(m, "one") ? 1 : 0;
     { const char *e = getenv("FHE_HIP_CHECK_INPUTS"); h->check_inputs = e && e[0] == '1'; }
     *out = h;
@@ -546,24 +549,29 @@ static int check_call(const fhe_rns_ntt *h, uint32_t batch, const char *what) {
     return FHE_OK;
 }
 
-static int ensure_ws(fhe_rns_ntt *h, size_t bytes) {
-    if (h->ws_bytes >= bytes) return FHE_OK;
-    // grow-only workspace of the general path (the reference mallocs/frees per multiply, src/ntt.cu:51-74)
+// Library-owned workspaces are per ENGINE and grow on demand; calls on one engine must be ordered on one stream (they share them).
+// A hipGraph captured from a call has the workspace addresses baked in, so growing (free + malloc) later would make every replay
+// touch freed memory: growth is refused while the engine's stream is capturing (call fhe_rns_ntt_reserve(h, max_batch) before the
+// capture; after it nothing here allocates), and a larger batch after a capture needs a re-capture -- see INTEGRATION.md.
+static int grow_ws(fhe_rns_ntt *h, void **ws, size_t *have, size_t bytes) {
+    if (*have >= bytes) return FHE_OK;
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(h->stream, &st) == hipSuccess && st != hipStreamCaptureStatusNone)
+        return fail(FHE_ERR_INVALID_ARG, "a library workspace would have to grow while the engine's stream is being captured into a graph: "
+                                         "call fhe_rns_ntt_reserve(h, batch) for the largest batch before the capture");
+    (void)hipGetLastError();
     HIP_TRY(hipStreamSynchronize(h->stream));
-    if (h->d_ws) { HIP_TRY(hipFree(h->d_ws)); h->d_ws = nullptr; h->ws_bytes = 0; }
-    HIP_TRY(hipMalloc(&h->d_ws, bytes));
-    h->ws_bytes = bytes;
+    if (*ws) { HIP_TRY(hipFree(*ws)); *ws = nullptr; *have = 0; }
+    HIP_TRY(hipMalloc(ws, bytes));
+    *have = bytes;
     return FHE_OK;
 }
-
-static int ensure_ws2(fhe_rns_ntt *h, size_t bytes) {
-    if (h->ws2_bytes >= bytes) return FHE_OK;
-    HIP_TRY(hipStreamSynchronize(h->stream));
-    if (h->d_ws2) { HIP_TRY(hipFree(h->d_ws2)); h->d_ws2 = nullptr; h->ws2_bytes = 0; }
-    HIP_TRY(hipMalloc(&h->d_ws2, bytes));
-    h->ws2_bytes = bytes;
-    return FHE_OK;
-}
+// d_ws : general paths (the reference mallocs/frees per multiply, src/ntt.cu:51-74) and the transformed b-side of the two-launch tensor product
+// d_ws2: c0, c1, c2 of the fused multiply + relinearise and the compact accumulators of a blind-rotation loop
+// d_ws3: the compact polynomials between the two launches of a two-pass transform (N beyond the LDS range)
+static int ensure_ws(fhe_rns_ntt *h, size_t bytes) { return grow_ws(h, &h->d_ws, &h->ws_bytes, bytes); }
+static int ensure_ws2(fhe_rns_ntt *h, size_t bytes) { return grow_ws(h, &h->d_ws2, &h->ws2_bytes, bytes); }
+static int ensure_ws3(fhe_rns_ntt *h, size_t bytes) { return grow_ws(h, &h->d_ws3, &h->ws3_bytes, bytes); }
 
 // ---- general (256-bit) path launchers -----------------------------------------------------------------
 // One radix-2^R global-memory pass over `polys` polynomials (src -> dst).  forward: stages s0 .. s0+R-1; inverse: index bits s0 .. s0+R-1.
@@ -659,16 +667,19 @@ static int run256_ew(fhe_rns_ntt *h, void *r, const void *a, const void *b, uint
 static int lds_width_id(const fhe_rns_ntt *h) {
     return h->width == FHE_WIDTH_32 ? 32 : h->width == FHE_WIDTH_52 ? 52 : h->width == FHE_WIDTH_64 ? 64 : 65;
 }
-// Two-pass transforms of the word-sized classes (log2 n = 13 + sub_top): one launch of the LOGN = 13 instance per pass.
-static int lds_big(fhe_rns_ntt *h, int op, void *dst, const void *src, const void *src2, uint32_t polys, bool rconst, const char *what) {
+// Two-pass transforms of the word-sized classes (log2 n = 13 + sub_top): one launch of the LOGN = 13 instance per pass.  Between the
+// two launches the polynomials are COMPACT (sizeof(residue) bytes per coefficient, d_ws3); *_compact tell which pointers are.
+static size_t residue_bytes(const fhe_rns_ntt *h) { return h->width == FHE_WIDTH_32 ? 4 : 8; }
+static int lds_big(fhe_rns_ntt *h, int op, void *dst, bool dst_compact, const void *src, bool src_compact, const void *src2, uint32_t polys, bool rconst,
+                   const char *what) {
     fhe_dev::lds_launch_fn fn = fhe_dev::lds_lookup(lds_width_id(h), 13);
     if (!fn) return fail(FHE_ERR_UNSUPPORTED, "no LDS instance for the two-pass transform");
     const uint32_t chunk_max = (65535u / h->L) * h->L;      // grid.y of the pass kernel; chunks keep the limb phase
-    const size_t poly_bytes = (size_t)h->n * 32;
+    const size_t dstep = (size_t)h->n * (dst_compact ? residue_bytes(h) : 32), sstep = (size_t)h->n * (src_compact ? residue_bytes(h) : 32);
     for (uint32_t done = 0; done < polys;) {
         const uint32_t chunk = polys - done < chunk_max ? polys - done : chunk_max;
-        fhe_dev::LdsArgs A{op, (char *)dst + done * poly_bytes, nullptr, nullptr, (const char *)src + done * poly_bytes, nullptr,
-                           src2 ? (const char *)src2 + done * poly_bytes : nullptr, nullptr, h->d_limbs, h->L, chunk, h->stream};
+        fhe_dev::LdsArgs A{op, (char *)dst + done * dstep, nullptr, nullptr, (const char *)src + done * sstep, nullptr,
+                           src2 ? (const char *)src2 + done * sstep : nullptr, nullptr, h->d_limbs, h->L, chunk, h->stream};
         A.top = h->sub_top; A.rconst = rconst;
         fn(A);
         done += chunk;
@@ -676,12 +687,14 @@ static int lds_big(fhe_rns_ntt *h, int op, void *dst, const void *src, const voi
     return post_launch(h->stream, what);
 }
 static int big_forward(fhe_rns_ntt *h, void *dst, const void *src, uint32_t polys) {
-    int rc = lds_big(h, fhe_dev::LDS_PASS_FWD, dst, src, nullptr, polys, false, "word_pass_kernel"); if (rc) return rc;
-    return lds_big(h, fhe_dev::LDS_SUB_FORWARD, dst, dst, nullptr, polys, false, "ntt_sub_kernel");
+    int rc = ensure_ws3(h, (size_t)polys * h->n * residue_bytes(h)); if (rc) return rc;
+    if ((rc = lds_big(h, fhe_dev::LDS_PASS_FWD, h->d_ws3, true, src, false, nullptr, polys, false, "word_pass_kernel"))) return rc;
+    return lds_big(h, fhe_dev::LDS_SUB_FORWARD, dst, false, h->d_ws3, true, nullptr, polys, false, "ntt_sub_kernel");
 }
 static int big_inverse(fhe_rns_ntt *h, void *data, uint32_t polys) {
-    int rc = lds_big(h, fhe_dev::LDS_SUB_INVERSE, data, data, nullptr, polys, false, "ntt_sub_kernel"); if (rc) return rc;
-    return lds_big(h, fhe_dev::LDS_PASS_INV, data, data, nullptr, polys, false, "word_pass_kernel");
+    int rc = ensure_ws3(h, (size_t)polys * h->n * residue_bytes(h)); if (rc) return rc;
+    if ((rc = lds_big(h, fhe_dev::LDS_SUB_INVERSE, h->d_ws3, true, data, false, nullptr, polys, false, "ntt_sub_kernel"))) return rc;
+    return lds_big(h, fhe_dev::LDS_PASS_INV, data, false, h->d_ws3, true, nullptr, polys, false, "word_pass_kernel");
 }
 
 // Key switch / external product of the 8-byte residues (and of the 4-byte residues at N = 2^15): ONE workgroup per (ciphertext, limb)
@@ -743,6 +756,21 @@ static int lds_check(fhe_rns_ntt *h, const void *d, uint32_t polys) {
     hipLaunchKernelGGL((fhe_dev::check_kernel<F>), dim3(ew_grid(halves)), dim3(256), 0, h->stream, (const V *)d,
                        (const fhe_dev::Limb<F> *)h->d_limbs, h->L, h->log_n, halves, h->d_flag);
     return post_launch(h->stream, "check_kernel");
+}
+
+template <class F>
+static int compact_poly_t(fhe_rns_ntt *h, void *out, const void *in, size_t containers) {
+    hipLaunchKernelGGL((fhe_dev::compact_kernel<F>), dim3(ew_grid(containers)), dim3(256), 0, h->stream, (typename F::E *)out, (const typename F::V16 *)in, containers);
+    return post_launch(h->stream, "compact_kernel");
+}
+static int compact_poly(fhe_rns_ntt *h, void *out, const void *in, size_t containers) {
+    switch (h->width) {
+        case FHE_WIDTH_32: return compact_poly_t<fhe_dev::F32>(h, out, in, containers);
+        case FHE_WIDTH_52: return compact_poly_t<fhe_dev::F52>(h, out, in, containers);
+        case FHE_WIDTH_64: return compact_poly_t<fhe_dev::F64>(h, out, in, containers);
+        case FHE_WIDTH_64X: return compact_poly_t<fhe_dev::F64X>(h, out, in, containers);
+        default: return fail(FHE_ERR_UNSUPPORTED, "compact polynomials exist on the word-sized classes only");
+    }
 }
 
 static int do_forward(fhe_rns_ntt *h, void *d_data, uint32_t batch) {
@@ -818,14 +846,14 @@ static int do_multiply(fhe_rns_ntt *h, void *d_r, const void *d_a, const void *d
     const uint32_t polys = batch * h->L;
     // d_r may alias d_a and/or d_b, as in the reference (which copies its operands first, src/ntt.cu:50-58): every
     // workgroup loads both of its operand polynomials completely before its first store, and the general path works on copies.
-    if (h->sub_top) {   // two-pass: the top stages of both operands go to the workspace (no copies), one fused launch over the 2^13 blocks, last pass in place
-        const size_t bytes = (size_t)polys * h->n * 32;
-        int rc = ensure_ws(h, 2 * bytes); if (rc) return rc;
-        char *wa = (char *)h->d_ws, *wb = d_b != d_a ? wa + bytes : wa;
-        if ((rc = lds_big(h, fhe_dev::LDS_PASS_FWD, wa, d_a, nullptr, polys, false, "word_pass_kernel"))) return rc;
-        if (d_b != d_a && (rc = lds_big(h, fhe_dev::LDS_PASS_FWD, wb, d_b, nullptr, polys, false, "word_pass_kernel"))) return rc;
-        if ((rc = lds_big(h, fhe_dev::LDS_SUB_MULTIPLY, d_r, wa, wb, polys, false, "ntt_sub_kernel"))) return rc;
-        return lds_big(h, fhe_dev::LDS_PASS_INV, d_r, d_r, nullptr, polys, true, "word_pass_kernel");
+    if (h->sub_top) {   // two-pass: the top stages of both operands go to the COMPACT workspace, one fused launch over the 2^13 blocks (compact in and out), last pass into the result
+        const size_t cbytes = (size_t)polys * h->n * residue_bytes(h);
+        int rc = ensure_ws3(h, 2 * cbytes); if (rc) return rc;
+        char *wa = (char *)h->d_ws3, *wb = d_b != d_a ? wa + cbytes : wa;
+        if ((rc = lds_big(h, fhe_dev::LDS_PASS_FWD, wa, true, d_a, false, nullptr, polys, false, "word_pass_kernel"))) return rc;
+        if (d_b != d_a && (rc = lds_big(h, fhe_dev::LDS_PASS_FWD, wb, true, d_b, false, nullptr, polys, false, "word_pass_kernel"))) return rc;
+        if ((rc = lds_big(h, fhe_dev::LDS_SUB_MULTIPLY, wa, true, wa, true, wb, polys, false, "ntt_sub_kernel"))) return rc;
+        return lds_big(h, fhe_dev::LDS_PASS_INV, d_r, false, wa, true, nullptr, polys, true, "word_pass_kernel");
     }
     if (h->width != FHE_WIDTH_256)
         return lds_run(h, fhe_dev::LDS_MULTIPLY, d_r, nullptr, nullptr, d_a, nullptr, d_b, nullptr, polys, "ntt_multiply_kernel");
@@ -887,6 +915,7 @@ extern "C" int fhe_rns_ntt_reserve(fhe_rns_ntt_t *h, uint32_t batch) {
     int rc = check_call(h, batch, "reserve"); if (rc) return rc;
     const size_t S = (size_t)h->L * h->n * 32;
     if ((rc = ensure_ws2(h, (size_t)batch * S))) return rc;            // >= 4 compact components of 8-byte residues, or one container component
+    if (h->sub_top && (rc = ensure_ws3(h, 2 * (size_t)batch * h->L * h->n * residue_bytes(h)))) return rc;   // two compact operands of a two-pass multiply
     if (h->width == FHE_WIDTH_256 || h->sub_top) rc = ensure_ws(h, 5 * (size_t)batch * S);
     else rc = ensure_ws(h, (size_t)batch * S / 2);                     // transformed b-side of the two-launch tensor product (2 compact components)
     return rc;
@@ -1130,6 +1159,15 @@ extern "C" int fhe_ct_relinearize(fhe_rns_ntt_t *h, const fhe_relin_keys_t *rk, 
         A.global_twiddles = h->global_twiddles;
         A.single_transforms = h->single_transforms;
         A.joint3 = use_joint3(h, false, false);
+        const bool c2_in_ws2 = h->d_ws2 && (const char *)d_c2 >= (const char *)h->d_ws2 && (const char *)d_c2 < (const char *)h->d_ws2 + h->ws2_bytes;
+        if (A.joint3 && h->width != FHE_WIDTH_32 && !h->no_c2_compaction && !c2_in_ws2) {   // (c2 already in the workspace: the composed multiply + relinearise under a testing switch)
+            // the three-array kernel re-reads c2 for every digit from each of the L limb workgroups: compact it once (S read, S/4 written)
+            // so that those L*K reads move S/4 instead of S (round 2 counters at N = 2^14, 6 x 40-bit: 2.6 x the algorithmic bytes)
+            const size_t containers = (size_t)batch * h->L * h->n;
+            if ((rc = ensure_ws2(h, containers * 8))) return rc;
+            if ((rc = compact_poly(h, h->d_ws2, d_c2, containers))) return rc;
+            A.a0 = h->d_ws2; A.c2_only_compact = true;
+        }
         fn(A);
         return post_launch(h->stream, "ntt_keyswitch_kernel");
     }

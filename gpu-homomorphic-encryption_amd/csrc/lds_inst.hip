@@ -15,18 +15,18 @@ void CAT(lds_launch_, FHE_FIELD, FHE_LOGN)(const LdsArgs &A) {
     const dim3 grid(A.polys), block(NttCfg<LOGN>::T);
     const Limb<F> *limbs = (const Limb<F> *)A.limbs;
     if constexpr (LOGN == 13) {          // this instance also serves N = 2^14 .. 2^16 in two passes (ntt_sub_kernel / word_pass_kernel)
-        using V = typename F::V16;
-        const dim3 pgrid((2u << 13) >> 8, A.polys), sgrid(A.polys << A.top);   // pass: two lanes per container of a 2^13-container column block
+        // pass: one lane per column of a 2^13-column block (forward: containers -> compact), two per column (inverse: compact -> containers)
+        const dim3 fgrid((1u << 13) >> 8, A.polys), igrid((2u << 13) >> 8, A.polys), sgrid(A.polys << A.top);
         switch (A.op) {
             case LDS_PASS_FWD:
-                if (A.top == 3) hipLaunchKernelGGL((word_pass_kernel<F, 3, true>), pgrid, dim3(256), 0, A.stream, (V *)A.r0, (const V *)A.a0, limbs, A.L, 16u, 0u);
-                else if (A.top == 2) hipLaunchKernelGGL((word_pass_kernel<F, 2, true>), pgrid, dim3(256), 0, A.stream, (V *)A.r0, (const V *)A.a0, limbs, A.L, 15u, 0u);
-                else hipLaunchKernelGGL((word_pass_kernel<F, 1, true>), pgrid, dim3(256), 0, A.stream, (V *)A.r0, (const V *)A.a0, limbs, A.L, 14u, 0u);
+                if (A.top == 3) hipLaunchKernelGGL((word_pass_kernel<F, 3, true>), fgrid, dim3(256), 0, A.stream, A.r0, A.a0, limbs, A.L, 16u, 0u);
+                else if (A.top == 2) hipLaunchKernelGGL((word_pass_kernel<F, 2, true>), fgrid, dim3(256), 0, A.stream, A.r0, A.a0, limbs, A.L, 15u, 0u);
+                else hipLaunchKernelGGL((word_pass_kernel<F, 1, true>), fgrid, dim3(256), 0, A.stream, A.r0, A.a0, limbs, A.L, 14u, 0u);
                 return;
             case LDS_PASS_INV:
-                if (A.top == 3) hipLaunchKernelGGL((word_pass_kernel<F, 3, false>), pgrid, dim3(256), 0, A.stream, (V *)A.r0, (const V *)A.a0, limbs, A.L, 16u, A.rconst ? 1u : 0u);
-                else if (A.top == 2) hipLaunchKernelGGL((word_pass_kernel<F, 2, false>), pgrid, dim3(256), 0, A.stream, (V *)A.r0, (const V *)A.a0, limbs, A.L, 15u, A.rconst ? 1u : 0u);
-                else hipLaunchKernelGGL((word_pass_kernel<F, 1, false>), pgrid, dim3(256), 0, A.stream, (V *)A.r0, (const V *)A.a0, limbs, A.L, 14u, A.rconst ? 1u : 0u);
+                if (A.top == 3) hipLaunchKernelGGL((word_pass_kernel<F, 3, false>), igrid, dim3(256), 0, A.stream, A.r0, A.a0, limbs, A.L, 16u, A.rconst ? 1u : 0u);
+                else if (A.top == 2) hipLaunchKernelGGL((word_pass_kernel<F, 2, false>), igrid, dim3(256), 0, A.stream, A.r0, A.a0, limbs, A.L, 15u, A.rconst ? 1u : 0u);
+                else hipLaunchKernelGGL((word_pass_kernel<F, 1, false>), igrid, dim3(256), 0, A.stream, A.r0, A.a0, limbs, A.L, 14u, A.rconst ? 1u : 0u);
                 return;
             case LDS_SUB_FORWARD:
                 hipLaunchKernelGGL((ntt_sub_kernel<F, 13, SUB_FORWARD, MULT_MINW>), sgrid, block, 0, A.stream, (char *)A.r0, (const char *)A.a0, (const char *)nullptr, limbs, A.L, A.top);
@@ -118,9 +118,14 @@ void CAT(lds_launch_, FHE_FIELD, FHE_LOGN)(const LdsArgs &A) {
                 }
             } else if constexpr (lds_keyswitch_split(sizeof(E), LOGN)) {
                 if (A.joint3) {
-                    if constexpr (lds_keyswitch_joint3(sizeof(E), LOGN))
-                        hipLaunchKernelGGL((ntt_keyswitch3_kernel<F, LOGN, 2, false>), grid, block, 0, A.stream, (char *)A.r0, (char *)A.r1,
-                                           (const char *)A.a0, (const char *)A.r0, (const char *)A.r1, (const E *)A.kb, (const E *)A.ka, limbs, A.L, A.K, A.w);
+                    if constexpr (lds_keyswitch_joint3(sizeof(E), LOGN)) {
+                        if (A.c2_only_compact)
+                            hipLaunchKernelGGL((ntt_keyswitch3_kernel<F, LOGN, 2, true, false>), grid, block, 0, A.stream, (char *)A.r0, (char *)A.r1,
+                                               (const char *)A.a0, (const char *)A.r0, (const char *)A.r1, (const E *)A.kb, (const E *)A.ka, limbs, A.L, A.K, A.w);
+                        else
+                            hipLaunchKernelGGL((ntt_keyswitch3_kernel<F, LOGN, 2, false>), grid, block, 0, A.stream, (char *)A.r0, (char *)A.r1,
+                                               (const char *)A.a0, (const char *)A.r0, (const char *)A.r1, (const E *)A.kb, (const E *)A.ka, limbs, A.L, A.K, A.w);
+                    }
                 } else
                     hipLaunchKernelGGL((ntt_keyswitch_kernel<F, LOGN, 2, true>), dim3(A.polys * 2), block, 0, A.stream, (char *)A.r0, (char *)A.r1,
                                        (const char *)A.a0, (const char *)A.r0, (const char *)A.r1, (const E *)A.kb, (const E *)A.ka, limbs, A.L, A.K, A.w);

@@ -65,6 +65,7 @@ struct LdsArgs {
     bool compact_c2 = false;             // fused multiply + relinearise (see lds_compact_c2): LDS_CT_MULTIPLY: r0, r1, r2 are compact workspace polynomials;
                                          // LDS_KEYSWITCH: a0 (c2) and the addends a1 (c0), b0 (c1) are, r0 / r1 are the container outputs
     bool in_compact = false, out_compact = false;   // LDS_EXTPROD (paired kernel only): the accumulator pair a0, a1 / r0, r1 is in compact form
+    bool c2_only_compact = false;        // LDS_KEYSWITCH with joint3, container addends: a0 (c2) is a compact polynomial (compacted by the host first)
     bool joint3 = false;                 // LDS_KEYSWITCH where lds_keyswitch_joint3 holds: one workgroup per limb with three live arrays (ntt_keyswitch3_kernel)
     void *ws = nullptr;                  // LDS_CT_MULTIPLY where !lds_ct_fused: 2 * polys * n residues of workspace for the transformed b-side
     uint32_t top = 0;                    // LDS_PASS_* / LDS_SUB_*: number of stages above the 2^13 blocks (log2 n = 13 + top)

@@ -42,6 +42,7 @@ struct NttCfg {
 // ---- index patterns: logical index = base(tid) | off(r), physical LDS slot = pbase(tid) + poff(r) ----
 // A : r <-> index bits [LOGT, LOGN)      (coalesced global order: consecutive lanes, consecutive coefficients)
 template <int LOGN> struct PatA {
+    static constexpr int LOGN_ = LOGN;
     using C = NttCfg<LOGN>;
     static constexpr int BIT0 = C::LOGT;
     static constexpr bool TW_UNIFORM = true;      // every stage on these bits has i >> (b+1) independent of tid
@@ -54,6 +55,7 @@ template <int LOGN> struct PatA {
 };
 // M : r <-> index bits [REM, REM+5)      (forward middle group)
 template <int LOGN> struct PatM {
+    static constexpr int LOGN_ = LOGN;
     using C = NttCfg<LOGN>;
     static constexpr int BIT0 = C::REM;
     static constexpr bool TW_UNIFORM = false;
@@ -66,6 +68,7 @@ template <int LOGN> struct PatM {
 };
 // Z : r <-> index bits [0, 5)            (32 consecutive coefficients per thread)
 template <int LOGN> struct PatZ {
+    static constexpr int LOGN_ = LOGN;
     static constexpr int BIT0 = 0;
     static constexpr bool TW_UNIFORM = false;
     static constexpr uint32_t TW_STRIDE = NttCfg<LOGN>::T;
@@ -77,6 +80,7 @@ template <int LOGN> struct PatZ {
 };
 // Y : r <-> index bits [5, 10)           (inverse middle group)
 template <int LOGN> struct PatY {
+    static constexpr int LOGN_ = LOGN;
     static constexpr int BIT0 = 5;
     static constexpr bool TW_UNIFORM = false;
     static constexpr uint32_t TW_STRIDE = NttCfg<LOGN>::T / 32;
@@ -98,6 +102,33 @@ __device__ __forceinline__ void lds_get(const E *lds, uint32_t tid, E (&x)[32]) 
     const E *p = lds + Pat::pbase(tid);
 #pragma unroll
     for (int r = 0; r < 32; r++) x[r] = p[Pat::poff(r)];
+}
+
+// Two arrays through ONE exchange image of element PAIRS (x0[r], x1[r]) side by side: the paired transforms of the 4-byte residues then
+// exchange with ds_write_b64 / ds_read_b64 -- half the LDS instructions of two 4-byte images (a 4-byte LDS read needs ~4 waves per
+// SIMD to reach its rate, these kernels run two: MI355X guide, LDS table), same padding rule in units of pairs, same footprint.
+// FHE_PAIR_EXCHANGE_B32 (compile-time A/B switch) keeps the round-2 form: two 4-byte images at lds and lds + LDS_ELEMS.
+template <class Pat, class E>
+__device__ __forceinline__ void lds_put2(E *lds, uint32_t tid, const E (&x0)[32], const E (&x1)[32]) {
+#ifdef FHE_PAIR_EXCHANGE_B32
+    lds_put<Pat>(lds, tid, x0); lds_put<Pat>(lds + NttCfg<Pat::LOGN_>::LDS_ELEMS, tid, x1);
+#else
+    typedef E E2 __attribute__((ext_vector_type(2)));
+    E2 *p = reinterpret_cast<E2 *>(lds) + Pat::pbase(tid);
+#pragma unroll
+    for (int r = 0; r < 32; r++) { E2 v = {x0[r], x1[r]}; p[Pat::poff(r)] = v; }
+#endif
+}
+template <class Pat, class E>
+__device__ __forceinline__ void lds_get2(const E *lds, uint32_t tid, E (&x0)[32], E (&x1)[32]) {
+#ifdef FHE_PAIR_EXCHANGE_B32
+    lds_get<Pat>(lds, tid, x0); lds_get<Pat>(lds + NttCfg<Pat::LOGN_>::LDS_ELEMS, tid, x1);
+#else
+    typedef E E2 __attribute__((ext_vector_type(2)));
+    const E2 *p = reinterpret_cast<const E2 *>(lds) + Pat::pbase(tid);
+#pragma unroll
+    for (int r = 0; r < 32; r++) { const E2 v = p[Pat::poff(r)]; x0[r] = v.x; x1[r] = v.y; }
+#endif
 }
 
 // ---- twiddle tables ----------------------------------------------------------------------------------------
@@ -293,7 +324,7 @@ __device__ __forceinline__ void fwd_core(typename F::E (&x)[32], typename F::E *
 // The key-switch and external-product kernels transform many digit polynomials under the same modulus.  Doing two of them
 // in lock step shares every twiddle load (one load feeds two butterflies), every barrier and every LDS wait between the two,
 // and doubles the independent work in flight per wave -- for the same register budget as holding the undecomposed limb
-// beside one digit polynomial.  x0 / x1 use their own exchange buffers lds0 / lds1.
+// beside one digit polynomial.  x0 / x1 travel through ONE exchange image of element pairs (lds_put2 / lds_get2).
 template <class F, int LOGN, class Pat, int KHI, int KLO>
 __device__ __forceinline__ void fwd_stages2(typename F::E (&x0)[32], typename F::E (&x1)[32], uint32_t tid, const typename F::TW *__restrict__ tw,
                                             const Limb<F> &P) {
@@ -313,22 +344,18 @@ __device__ __forceinline__ void fwd_stages2(typename F::E (&x0)[32], typename F:
 }
 // PRESYNC as in fwd_core: the barrier that ends the previous transforms' use of the exchange buffers sits after the first group.
 template <class F, int LOGN, bool PRESYNC = false>
-__device__ __forceinline__ void fwd_core2(typename F::E (&x0)[32], typename F::E (&x1)[32], typename F::E *lds0, typename F::E *lds1, uint32_t tid,
+__device__ __forceinline__ void fwd_core2(typename F::E (&x0)[32], typename F::E (&x1)[32], typename F::E *lds, uint32_t tid,
                                           const Limb<F> &P) {
     using C = NttCfg<LOGN>;
     fwd_stages2<F, LOGN, PatA<LOGN>, 4, 0>(x0, x1, tid, P.tw, P);
     if constexpr (PRESYNC) __syncthreads();
-    lds_put<PatA<LOGN>>(lds0, tid, x0);
-    lds_put<PatA<LOGN>>(lds1, tid, x1);
+    lds_put2<PatA<LOGN>>(lds, tid, x0, x1);
     __syncthreads();
-    lds_get<PatM<LOGN>>(lds0, tid, x0);
-    lds_get<PatM<LOGN>>(lds1, tid, x1);
+    lds_get2<PatM<LOGN>>(lds, tid, x0, x1);
     fwd_stages2<F, LOGN, PatM<LOGN>, 4, 0>(x0, x1, tid, P.tw, P);
-    lds_put<PatM<LOGN>>(lds0, tid, x0);
-    lds_put<PatM<LOGN>>(lds1, tid, x1);
+    lds_put2<PatM<LOGN>>(lds, tid, x0, x1);       // same slots this thread just read: no barrier needed before
     __syncthreads();
-    lds_get<PatZ<LOGN>>(lds0, tid, x0);
-    lds_get<PatZ<LOGN>>(lds1, tid, x1);
+    lds_get2<PatZ<LOGN>>(lds, tid, x0, x1);
     fwd_stages2<F, LOGN, PatZ<LOGN>, C::REM - 1, 0>(x0, x1, tid, P.tw, P);
 }
 
@@ -379,24 +406,20 @@ __device__ __forceinline__ void inv_stages2(typename F::E (&x0)[32], typename F:
     }
 }
 template <class F, int LOGN, bool PRESYNC = false>
-__device__ __forceinline__ void inv_core2(typename F::E (&x0)[32], typename F::E (&x1)[32], typename F::E *lds0, typename F::E *lds1, uint32_t tid,
+__device__ __forceinline__ void inv_core2(typename F::E (&x0)[32], typename F::E (&x1)[32], typename F::E *lds, uint32_t tid,
                                           const Limb<F> &P, typename F::E ninv, typename F::E ninv_s, typename F::E ninvw, typename F::E ninvw_s) {
     using C = NttCfg<LOGN>;
     inv_stages2<F, LOGN, PatZ<LOGN>, 0, 4>(x0, x1, tid, P.itw, P);
     F::regroup(x0, P.q, P.qinv); F::regroup(x1, P.q, P.qinv);
     if constexpr (PRESYNC) __syncthreads();
-    lds_put<PatZ<LOGN>>(lds0, tid, x0);
-    lds_put<PatZ<LOGN>>(lds1, tid, x1);
+    lds_put2<PatZ<LOGN>>(lds, tid, x0, x1);
     __syncthreads();
-    lds_get<PatY<LOGN>>(lds0, tid, x0);
-    lds_get<PatY<LOGN>>(lds1, tid, x1);
+    lds_get2<PatY<LOGN>>(lds, tid, x0, x1);
     inv_stages2<F, LOGN, PatY<LOGN>, 0, 4>(x0, x1, tid, P.itw, P);
     F::regroup(x0, P.q, P.qinv); F::regroup(x1, P.q, P.qinv);
-    lds_put<PatY<LOGN>>(lds0, tid, x0);
-    lds_put<PatY<LOGN>>(lds1, tid, x1);
+    lds_put2<PatY<LOGN>>(lds, tid, x0, x1);
     __syncthreads();
-    lds_get<PatA<LOGN>>(lds0, tid, x0);
-    lds_get<PatA<LOGN>>(lds1, tid, x1);
+    lds_get2<PatA<LOGN>>(lds, tid, x0, x1);
     inv_stages2<F, LOGN, PatA<LOGN>, 5 - C::REM, 3>(x0, x1, tid, P.itw, P);
     inv_last_stage<F>(x0, P.q, P.q2, ninv, ninv_s, ninvw, ninvw_s);
     inv_last_stage<F>(x1, P.q, P.q2, ninv, ninv_s, ninvw, ninvw_s);
@@ -494,9 +517,15 @@ ntt_multiply_kernel(char *res, const char *a, const char *b,      // no __restri
 // ---- transforms larger than the LDS range: N = 2^(LOGN + k), k = 1..3 --------------------------------------------------------------
 // The top k stages (forward) / last k stages (inverse) run as one register-only pass over global memory (word_pass_kernel below);
 // the 2^k blocks of 2^LOGN consecutive coefficients are then independent sub-transforms, each one workgroup of the LDS-resident
-// machinery above with the big transform's twiddles (SUB = true, pre = 2^k + block).  HBM traffic: 4 S per transform, 9 S per fused
-// multiply (top(a) + top(b) into the workspace 4 S, sub-multiply 3 S, last pass 2 S).
+// machinery above with the big transform's twiddles (SUB = true, pre = 2^k + block).
+// What crosses between the two launches of ONE call is a COMPACT polynomial (sizeof(E) bytes per coefficient in natural order, library
+// workspace, see load_A_compact) -- only the call's own operands and results are 32-byte containers.  HBM traffic (4-byte residues):
+//   transform  : S + S/8 (pass) + S/8 + S (sub-transforms)                     = 2.25 S   (round 2, container workspace: 4 S)
+//   multiply   : 2 (S + S/8) (top passes of a, b) + 3 S/8 (sub-multiply) + S/8 + S (last pass) = 3.75 S   (round 2: 9 S)
+// and S/4 instead of S/8 per compact polynomial for the 8-byte residues (2.5 S / 4.5 S).
 // grid.x = polys << k: workgroup g handles block g & (2^k - 1) of polynomial g >> k.
+// SUB_FORWARD: compact in, containers out.  SUB_INVERSE: containers in, compact out.  SUB_MULTIPLY: compact a, b in, compact out (res may
+// be a: a workgroup reads its whole block of both operands before it stores).
 enum { SUB_FORWARD = 0, SUB_INVERSE = 1, SUB_MULTIPLY = 2 };
 template <class F, int LOGN, int MODE, int MINW = 1>
 __global__ void __launch_bounds__(NttCfg<LOGN>::T, MINW)
@@ -506,22 +535,27 @@ ntt_sub_kernel(char *res, const char *a, const char *b, const Limb<F> *__restric
     __shared__ E lds[C::LDS_ELEMS];
     const uint32_t tid = threadIdx.x, p = blockIdx.x >> k, blk = blockIdx.x & ((1u << k) - 1), pre = (1u << k) + blk;
     const Limb<F> P = limbs[p % L];
-    const size_t off = (size_t)blockIdx.x * (C::N * 32);          // polynomial p starts at p << (LOGN + k) containers
+    const size_t off = (size_t)blockIdx.x * (C::N * 32);          // containers: polynomial p starts at p << (LOGN + k) containers
+    const size_t offc = (size_t)blockIdx.x * C::N;                // compact: the same block in residues
     E x[32];
-    load_A<F, LOGN>(a + off, tid, x);
     if constexpr (MODE == SUB_FORWARD) {
+        load_A_compact<F, LOGN>(reinterpret_cast<const E *>(a) + offc, tid, x);
         fwd_core<F, LOGN, false, false, true>(x, lds, tid, P, nullptr, pre);
 #pragma unroll
         for (int r = 0; r < 32; r++) x[r] = F::canon_fwd(x[r], P.q, P.q2, P.qinv);
         lds_put<PatZ<LOGN>>(lds, tid, x);
+        __syncthreads();
+        store_from_lds<F, LOGN>(res + off, lds, tid);
     } else {
         if constexpr (MODE == SUB_INVERSE) {
+            load_A<F, LOGN>(a + off, tid, x);
             lds_put<PatA<LOGN>>(lds, tid, x);
             __syncthreads();
             lds_get<PatZ<LOGN>>(lds, tid, x);
         } else {
             E y[32];
-            load_A<F, LOGN>(b + off, tid, y);
+            load_A_compact<F, LOGN>(reinterpret_cast<const E *>(a) + offc, tid, x);
+            load_A_compact<F, LOGN>(reinterpret_cast<const E *>(b) + offc, tid, y);
             fwd_core<F, LOGN, false, false, true>(x, lds, tid, P, nullptr, pre);
 #pragma unroll
             for (int r = 0; r < 32; r++) x[r] = F::canon_fwd(x[r], P.q, P.q2, P.qinv);
@@ -533,33 +567,40 @@ ntt_sub_kernel(char *res, const char *a, const char *b, const Limb<F> *__restric
         inv_core<F, LOGN, false, false, true>(x, lds, tid, P, P.ninv, P.ninv_s, P.ninvw, P.ninvw_s, nullptr, pre);
 #pragma unroll
         for (int r = 0; r < 32; r++) x[r] = F::canon_inv(x[r], P.q);
-        lds_put<PatA<LOGN>>(lds, tid, x);
+        store_A_compact<F, LOGN>(reinterpret_cast<E *>(res) + offc, tid, x);     // pattern A registers: consecutive lanes, consecutive words
     }
-    __syncthreads();
-    store_from_lds<F, LOGN>(res + off, lds, tid);
 }
 
 // One register-only pass over R <= 3 stages of a transform of 2^log_n coefficients on the field type: FWD: the top R stages (index
 // bits log_n-1 .. log_n-R), natural-order canonical input; !FWD: the last R stages (the same bits, ascending) with the n^-1 scaling
 // folded into the final butterfly (rconst: the constants that also absorb the 2^-W of a fused pointwise product).  Canonical
-// residues in and out (full containers).  src may differ from dst.
-// Lanes work in pairs: lanes 2c and 2c+1 both load the low word of container c (one request) and run the same butterflies; the even
-// lane then stores the value half of each output container and the odd lane the zero half, so a wave instruction writes 1 KiB of
-// consecutive bytes (like store_from_lds) instead of every other 16 bytes of 2 KiB: 5.5 instead of 4.1 TB/s on the pass, whose
-// arithmetic is far from binding (12 butterflies per 8 containers; one column per lane with the outputs exchanged by shuffles was
-// measured for the 8-byte fields and is no faster).  grid = (2^(log_n - R + 1) / 256, polys).
+// residues in and out.
+// FWD : containers (src, the caller's operand) -> compact (dst, workspace): ONE lane per column of 2^R coefficients, every store
+//       instruction of a wave writes 64 consecutive residues.
+// !FWD: compact (src, workspace) -> containers (dst, the caller's result): lanes work in PAIRS -- lanes 2c and 2c+1 load the same
+//       compact words and run the same butterflies; the even lane stores the value half of each output container and the odd lane the
+//       zero half, so a wave instruction writes 1 KiB of consecutive bytes (like store_from_lds) instead of every other 16 bytes of
+//       2 KiB (5.5 instead of 4.1 TB/s on the container-to-container pass of round 2; the arithmetic is far from binding).
+// grid = (columns * (FWD ? 1 : 2) / 256, polys), columns = 2^(log_n - R).
 template <class F, int R, bool FWD>
 __global__ void __launch_bounds__(256)
-word_pass_kernel(typename F::V16 *dst, const typename F::V16 *src, const Limb<F> *__restrict__ limbs, uint32_t L, uint32_t log_n, uint32_t rconst) {
+word_pass_kernel(void *dst, const void *src, const Limb<F> *__restrict__ limbs, uint32_t L, uint32_t log_n, uint32_t rconst) {
     using E = typename F::E;
-    const uint32_t g = blockIdx.x * 256 + threadIdx.x, u = g >> 1, half = g & 1;    // u < 2^log_n >> R by construction of the grid
+    using V = typename F::V16;
+    const uint32_t g = blockIdx.x * 256 + threadIdx.x, u = FWD ? g : g >> 1, half = FWD ? 0u : g & 1;   // u < 2^log_n >> R by construction of the grid
     const uint32_t p = blockIdx.y;
     const Limb<F> P = limbs[p % L];
     const uint32_t b_lo = log_n - R;
-    const typename F::V16 *in = src + ((size_t)p << (log_n + 1)); typename F::V16 *out = dst + ((size_t)p << (log_n + 1));
     E x[1 << R];
+    if constexpr (FWD) {
+        const V *in = reinterpret_cast<const V *>(src) + ((size_t)p << (log_n + 1));
 #pragma unroll
-    for (int k = 0; k < (1 << R); k++) x[k] = F::load_low(in + 2 * ((size_t)u + ((size_t)k << b_lo)));
+        for (int k = 0; k < (1 << R); k++) x[k] = F::load_low(in + 2 * ((size_t)u + ((size_t)k << b_lo)));
+    } else {
+        const E *in = reinterpret_cast<const E *>(src) + ((size_t)p << log_n);
+#pragma unroll
+        for (int k = 0; k < (1 << R); k++) x[k] = in[(size_t)u + ((size_t)k << b_lo)];
+    }
 #pragma unroll
     for (int j = 0; j < R; j++) {
         const int pos = FWD ? R - 1 - j : j;                                  // k-bit of this stage; index bit b_lo + pos
@@ -579,10 +620,17 @@ word_pass_kernel(typename F::V16 *dst, const typename F::V16 *src, const Limb<F>
             else F::inv_bfly(x[k], x[k | (1 << pos)], w, P);
         }
     }
+    if constexpr (FWD) {
+        E *out = reinterpret_cast<E *>(dst) + ((size_t)p << log_n);
 #pragma unroll
-    for (int k = 0; k < (1 << R); k++) {
-        const E v = FWD ? F::canon_fwd(x[k], P.q, P.q2, P.qinv) : F::canon_inv(F::regroup1(x[k], P.q, P.qinv), P.q);
-        __builtin_nontemporal_store(F::pack(half ? (E)0 : v), out + 2 * ((size_t)u + ((size_t)k << b_lo)) + half);
+        for (int k = 0; k < (1 << R); k++) out[(size_t)u + ((size_t)k << b_lo)] = F::canon_fwd(x[k], P.q, P.q2, P.qinv);
+    } else {
+        V *out = reinterpret_cast<V *>(dst) + ((size_t)p << (log_n + 1));
+#pragma unroll
+        for (int k = 0; k < (1 << R); k++) {
+            const E v = F::canon_inv(F::regroup1(x[k], P.q, P.qinv), P.q);
+            __builtin_nontemporal_store(F::pack(half ? (E)0 : v), out + 2 * ((size_t)u + ((size_t)k << b_lo)) + half);
+        }
     }
 }
 
@@ -928,7 +976,7 @@ ntt_keyswitch_kernel(char *c0, char *c1, const char *__restrict__ c2, const char
 // polynomial; the c2 limb is re-read for every digit (compact workspace: N * 8 bytes from L2) instead of being held.  Against the SPLIT
 // form of ntt_keyswitch_kernel (two workgroups per limb, one per key half, every digit transform computed twice) this halves the
 // transforms; the register file is exceeded by what the compiler parks in scratch around the transforms.
-template <class F, int LOGN, int MINW = 1, bool COMPACT = false>
+template <class F, int LOGN, int MINW = 1, bool COMPACT = false, bool ADD_COMPACT = COMPACT>
 __global__ void __launch_bounds__(NttCfg<LOGN>::T, MINW)
 ntt_keyswitch3_kernel(char *c0, char *c1, const char *__restrict__ c2, const char *add0, const char *add1,
                       const typename F::E *__restrict__ kb, const typename F::E *__restrict__ ka,
@@ -973,7 +1021,7 @@ ntt_keyswitch3_kernel(char *c0, char *c1, const char *__restrict__ c2, const cha
     F::regroup(acc0, P.q, P.qinv);
     inv_core<F, LOGN, false, true>(acc0, lds, tid, P, P.ninv, P.ninv_s, P.ninvw, P.ninvw_s);
     __builtin_amdgcn_sched_barrier(0);
-    load_poly_buf<F, LOGN, COMPACT>(add0 + (size_t)p * (C::N * (COMPACT ? sizeof(E) : 32)), tid, d);
+    load_poly_buf<F, LOGN, ADD_COMPACT>(add0 + (size_t)p * (C::N * (ADD_COMPACT ? sizeof(E) : 32)), tid, d);
 #pragma unroll
     for (int r = 0; r < 32; r++) acc0[r] = F::ew_add(F::canon_inv(acc0[r], P.q), d[r], P.q);
     lds_put<PatA<LOGN>>(lds, tid, acc0);
@@ -983,7 +1031,7 @@ ntt_keyswitch3_kernel(char *c0, char *c1, const char *__restrict__ c2, const cha
     F::regroup(acc1, P.q, P.qinv);
     __syncthreads();
     inv_core<F, LOGN>(acc1, lds, tid, P, P.ninv, P.ninv_s, P.ninvw, P.ninvw_s);
-    load_poly_buf<F, LOGN, COMPACT>(add1 + (size_t)p * (C::N * (COMPACT ? sizeof(E) : 32)), tid, d);
+    load_poly_buf<F, LOGN, ADD_COMPACT>(add1 + (size_t)p * (C::N * (ADD_COMPACT ? sizeof(E) : 32)), tid, d);
 #pragma unroll
     for (int r = 0; r < 32; r++) acc1[r] = F::ew_add(F::canon_inv(acc1[r], P.q), d[r], P.q);
     lds_put<PatA<LOGN>>(lds, tid, acc1);
@@ -1019,7 +1067,12 @@ __device__ __forceinline__ void rotate_through_lds(typename F::E *lds, uint32_t 
     using C = NttCfg<LOGN>;
     using E = typename F::E;
     __syncthreads();                                // the previous transform's last reads of the exchange buffer are over
-    lds_put<PatA<LOGN>>(lds, tid, x);
+    // UNPADDED image for this one round trip: both the store (lane-consecutive, pattern A order) and the rotated read-back
+    // (lane-consecutive from an arbitrary start) are conflict-free without padding, whereas on the padded image a read that does
+    // not start on a multiple of 32 crosses one pad slot inside a 32-lane group: a 2-way conflict on every instruction (round 2:
+    // SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.07 in the external-product kernels, the only family with conflicts).
+#pragma unroll
+    for (int r = 0; r < 32; r++) lds[tid + (uint32_t)r * C::T] = x[r];
     __syncthreads();
     const uint32_t k0 = tid + 2 * C::N - a;
 #pragma unroll
@@ -1027,7 +1080,7 @@ __device__ __forceinline__ void rotate_through_lds(typename F::E *lds, uint32_t 
         uint32_t k = (k0 + (uint32_t)r * C::T) & (2 * C::N - 1);      // (i - a) mod 2n
         const bool neg = k >= (uint32_t)C::N;                         // X^n = -1
         k &= C::N - 1;
-        E v = lds[k + (k >> 5)];                                      // consecutive lanes, consecutive slots: conflict-free like pattern A
+        E v = lds[k];                                                 // consecutive lanes, consecutive slots (the wrap at n keeps banks distinct)
         if (neg) v = F::ew_sub((E)0, v, qj);
         x[r] = F::ew_sub(v, x[r], qj);
     }
@@ -1269,11 +1322,11 @@ __device__ __forceinline__ void mac_keys2(typename F::E (&acc0)[32], typename F:
 // dst0 / dst1: base pointers of the output buffers (containers, or compact polynomials when COMPACT_OUT)
 template <class F, int LOGN, bool COMPACT = false, bool COMPACT_OUT = false>
 __device__ __forceinline__ void finish_pair(typename F::E (&acc0)[32], typename F::E (&acc1)[32], typename F::E (&t0)[32], typename F::E (&t1)[32],
-                                            typename F::E *lds0, typename F::E *lds1, uint32_t tid, const Limb<F> &P,
+                                            typename F::E *lds, uint32_t tid, const Limb<F> &P,
                                             const char *add0, const char *add1, size_t p, char *dst0, char *dst1) {
     load_src<F, LOGN, COMPACT>(add0, p, tid, t0);   // issued first: the HBM latency hides under the inverse transforms
     load_src<F, LOGN, COMPACT>(add1, p, tid, t1);
-    inv_core2<F, LOGN, true>(acc0, acc1, lds0, lds1, tid, P, P.ninv, P.ninv_s, P.ninvw, P.ninvw_s);
+    inv_core2<F, LOGN, true>(acc0, acc1, lds, tid, P, P.ninv, P.ninv_s, P.ninvw, P.ninvw_s);
 #pragma unroll
     for (int r = 0; r < 32; r++) {
         acc0[r] = F::ew_add(F::canon_inv(acc0[r], P.q), t0[r], P.q);
@@ -1283,6 +1336,8 @@ __device__ __forceinline__ void finish_pair(typename F::E (&acc0)[32], typename 
         store_A_compact<F, LOGN>(reinterpret_cast<typename F::E *>(dst0) + p * NttCfg<LOGN>::N, tid, acc0);
         store_A_compact<F, LOGN>(reinterpret_cast<typename F::E *>(dst1) + p * NttCfg<LOGN>::N, tid, acc1);
     } else {
+        typename F::E *lds0 = lds, *lds1 = lds + NttCfg<LOGN>::LDS_ELEMS;   // two 4-byte images for the container stores
+        __syncthreads();                       // every pair read of the last exchange is over before the images are rewritten
         lds_put<PatA<LOGN>>(lds0, tid, acc0);
         lds_put<PatA<LOGN>>(lds1, tid, acc1);
         __syncthreads();
@@ -1324,7 +1379,7 @@ ntt_keyswitch2_kernel(char *c0, char *c1, const char *__restrict__ c2, const cha
         }
 #pragma unroll
         for (int r = 0; r < 32; r++) d1[r] = F::digit(d1[r], k1 * w, w);
-        fwd_core2<F, LOGN, true>(d0, d1, lds, lds + C::LDS_ELEMS, tid, P);
+        fwd_core2<F, LOGN, true>(d0, d1, lds, tid, P);
         mac_keys2<F>(acc0, acc1, d0, d1, kb, ka, ((size_t)jk * L + i) * C::N, kb, ka, ((size_t)(jk + 1) * L + i) * C::N, tid, C::T, P);
     }
     if (jk < LK) {                                        // odd number of digit polynomials: the last one alone
@@ -1335,7 +1390,7 @@ ntt_keyswitch2_kernel(char *c0, char *c1, const char *__restrict__ c2, const cha
         fwd_core<F, LOGN, false, true>(d0, lds, tid, P);
         mac_keys<F>(acc0, acc1, d0, kb, ka, ((size_t)jk * L + i) * C::N, tid, C::T, P);
     }
-    finish_pair<F, LOGN, COMPACT>(acc0, acc1, d0, d1, lds, lds + C::LDS_ELEMS, tid, P, add0, add1, p, c0, c1);
+    finish_pair<F, LOGN, COMPACT>(acc0, acc1, d0, d1, lds, tid, P, add0, add1, p, c0, c1);
 }
 
 // IN_COMPACT / OUT_COMPACT: the accumulator pair is read from / written to compact polynomials (load_A_compact): inside fhe_blind_rotate
@@ -1378,11 +1433,11 @@ ntt_extprod2_kernel(char *__restrict__ out0, char *__restrict__ out1, const char
         }
 #pragma unroll
         for (int r = 0; r < 32; r++) d1[r] = F::digit(d1[r], k1 * w, w);
-        fwd_core2<F, LOGN, true>(d0, d1, lds, lds + C::LDS_ELEMS, tid, P);
+        fwd_core2<F, LOGN, true>(d0, d1, lds, tid, P);
         mac_keys2<F>(acc0, acc1, d0, d1, c0i ? kb1 : kb0, c0i ? ka1 : ka0, ((size_t)jk0 * L + i) * C::N, c1i ? kb1 : kb0, c1i ? ka1 : ka0,
                      ((size_t)jk1 * L + i) * C::N, tid, C::T, P);
     }
-    finish_pair<F, LOGN, IN_COMPACT, OUT_COMPACT>(acc0, acc1, d0, d1, lds, lds + C::LDS_ELEMS, tid, P, in0, in1, p, out0, out1);
+    finish_pair<F, LOGN, IN_COMPACT, OUT_COMPACT>(acc0, acc1, d0, d1, lds, tid, P, in0, in1, p, out0, out1);
 }
 
 }  // namespace fhe_dev

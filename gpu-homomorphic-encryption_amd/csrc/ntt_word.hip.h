@@ -26,6 +26,15 @@ ew_kernel(typename F::V16 *r, const typename F::V16 *a, const typename F::V16 *b
     }
 }
 
+// containers -> compact polynomial (sizeof(E) bytes per coefficient, natural order): the operand that every limb workgroup of a
+// key-switch call re-reads once per digit (c2) is compacted first, so the re-reads move S/4 (S/8) instead of S.  One lane per container.
+template <class F>
+__global__ void __launch_bounds__(256)
+compact_kernel(typename F::E *__restrict__ out, const typename F::V16 *__restrict__ in, size_t containers) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < containers; g += stride) out[g] = F::load_low(in + 2 * g);
+}
+
 // Canonical-input scan: flags any container whose value is >= q or whose upper words are not zero.
 template <class F>
 __global__ void __launch_bounds__(256)

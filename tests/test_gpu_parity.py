@@ -369,6 +369,31 @@ def test_relinearize_matches_oracle(eng, oracle, monkeypatch, n, spec, w, batch,
         e.import_relin_keys(w, dkb[:-1], dka[:-1])
 
 
+@pytest.mark.parametrize("n,spec,w,batch", [(16384, ("bits", 40, 3), 16, 3), (8192, ("bits", 40, 3), 20, 9), (16384, ("bits", 60, 2), 32, 2),
+                                            (4096, ("bits", 64, 2), 32, 5), (8192, ("bits", 62, 1), 16, 2)])
+@pytest.mark.parametrize("compaction", [True, False])
+def test_relinearize_8_byte_fields_with_and_without_c2_compaction(eng, oracle, monkeypatch, n, spec, w, batch, compaction):
+    """Stand-alone relinearisation of the 8-byte fields: c2 is compacted once (compact_kernel) and the three-array kernel re-reads the
+    compact copy per digit; FHE_HIP_NO_C2_COMPACTION=1 keeps the container reads of round 2.  Both against the oracle; c2 is left untouched."""
+    if not compaction:
+        monkeypatch.setenv("FHE_HIP_NO_C2_COMPACTION", "1")
+    moduli = _moduli(spec, n); L = len(moduli)
+    e = eng.RnsNttEngine(n, moduli); rp = oracle.RnsPlan(n, moduli)
+    K = e.relin_num_digits(w)
+    kb = _random_keys(moduli, n, L * K, 300); ka = _random_keys(moduli, n, L * K, 700)
+    c0, c1, c2 = (rns_poly(s, moduli, n, batch) for s in (61, 62, 63))
+    rk = e.import_relin_keys(w, [_up(eng, k) for k in kb], [_up(eng, k) for k in ka])
+    d0, d1, d2 = _up(eng, c0), _up(eng, c1), _up(eng, c2)
+    e.relinearize(rk, d0, d1, d2, batch)
+    w0, w1 = rp.relinearize(w, c0, c1, c2, kb, ka, threads=8)
+    assert np.array_equal(d0.download(c0.shape), w0) and np.array_equal(d1.download(c0.shape), w1)
+    assert np.array_equal(d2.download(c0.shape), c2)
+    # a second call with a smaller batch re-uses the (larger) workspace
+    d0, d1 = _up(eng, c0), _up(eng, c1)
+    e.relinearize(rk, d0, d1, d2, 1)
+    assert np.array_equal(d0.download(c0.shape)[:1], w0[:1]) and np.array_equal(d0.download(c0.shape)[1:], c0[1:])
+
+
 @pytest.mark.parametrize("bits", [30, 40, 60, 64])
 def test_relinearize_general_path_on_word_sized_moduli(eng, oracle, monkeypatch, bits):
     """The unfused composition (digit embedding, batched NTT, MAC) must agree with the fused key-switch kernels."""
