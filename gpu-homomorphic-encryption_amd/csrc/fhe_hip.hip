@@ -244,13 +244,16 @@ struct fhe_rns_ntt {
     uint32_t n = 0, log_n = 0, L = 0;
     int width = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
+    hipStream_t aux_stream = nullptr;   // second stream of the overlapped one-call multiply (fork / join with events around it)
+    hipEvent_t ev_chunk[16] = {}, ev_join = nullptr;   // tensor product of chunk i done (engine stream) -> key switch of chunk i may start (second stream)
+    uint32_t overlap_chunks = 4;        // FHE_HIP_CT_RELIN_CHUNKS: pieces the one-call multiply is cut into (1 = one stream, as in round 2)
     void *d_limbs = nullptr;            // owned by d_tables
     void *d_wlimbs = nullptr;           // FHE_WIDTH_256: WLimb<wide_nl>[L] for the NTT kernels of ntt_wide.hip.h (owned by d_tables)
     uint32_t sub_top = 0;               // word-sized classes beyond the LDS range: log2 n = 13 + sub_top (two-pass transforms), else 0
     int wide_nl = 0;                    // FHE_WIDTH_256: 64-bit limbs per residue in those kernels (2: q < 2^127, 4: q < 2^255)
     bool wide_tiles = true;             // FHE_HIP_NO_WIDE_TILES=1: every stage as a global-memory pass (cross-check / A-B)
     bool no_square = false, single_transforms = false, global_twiddles = false, check_inputs = false, no_fused_keyswitch = false,
-         no_word_conversions = false, no_fused_blind_rotate = false, no_fused_ct_relin = false, no_compact_blind_rotate = false, no_two_launch_ct = false, split_keyswitch = false, no_c2_compaction = false;
+         no_word_conversions = false, no_fused_blind_rotate = false, no_fused_ct_relin = false, no_compact_blind_rotate = false, no_two_launch_ct = false, split_keyswitch = false, no_c2_compaction = false, no_prerotation = false;
     int ct_form_force = 0;                         // FHE_HIP_CT_FORM: 0 = by field and size, 1 = one-launch tensor product where it exists, 2 = two-launch where it exists   // environment switches, read once at creation
     std::vector<void *> d_tables;
     void *d_ws = nullptr; size_t ws_bytes = 0;
@@ -282,6 +285,9 @@ static void destroy_impl(fhe_rns_ntt *h) {
     if (h->d_ws3) (void)hipFree(h->d_ws3);
     if (h->d_cdt) (void)hipFree(h->d_cdt);
     if (h->d_flag) (void)hipFree(h->d_flag);
+    if (h->aux_stream) (void)hipStreamDestroy(h->aux_stream);
+    for (hipEvent_t e : h->ev_chunk) if (e) (void)hipEventDestroy(e);
+    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
 }
@@ -534,6 +540,8 @@ static int create_impl(fhe_rns_ntt **out, uint32_t n, const uint64_t (*moduli)[4
     h->no_compact_blind_rotate = getenv("FHE_HIP_NO_COMPACT_BLIND_ROTATE") != nullptr;
     h->no_two_launch_ct = getenv("FHE_HIP_NO_TWO_LAUNCH_CT") != nullptr;
     h->split_keyswitch = getenv("FHE_HIP_SPLIT_KEYSWITCH") != nullptr;
+    if (const char *m = getenv("FHE_HIP_CT_RELIN_CHUNKS")) { const int v = atoi(m); h->overlap_chunks = v < 1 ? 1 : v > 16 ? 16 : (uint32_t)v; }
+    h->no_prerotation = getenv("FHE_HIP_NO_PREROTATION") != nullptr;       // blind-rotation loop of the three-array kernels: monomial factor inside the kernel, per digit (A/B, cross-check)
     h->no_c2_compaction = getenv("FHE_HIP_NO_C2_COMPACTION") != nullptr;   // stand-alone relinearisation of the 8-byte fields: c2 read as containers (A/B, cross-check)
     if (const char *m = getenv("FHE_HIP_CT_FORM")) h->ct_form_force = !strcmp(m, "two") ? 2 : !strcmp(m, "one") ? 1 : 0;
     { const char *e = getenv("FHE_HIP_CHECK_INPUTS"); h->check_inputs = e && e[0] == '1'; }
@@ -769,6 +777,22 @@ static int compact_poly(fhe_rns_ntt *h, void *out, const void *in, size_t contai
         case FHE_WIDTH_52: return compact_poly_t<fhe_dev::F52>(h, out, in, containers);
         case FHE_WIDTH_64: return compact_poly_t<fhe_dev::F64>(h, out, in, containers);
         case FHE_WIDTH_64X: return compact_poly_t<fhe_dev::F64X>(h, out, in, containers);
+        default: return fail(FHE_ERR_UNSUPPORTED, "compact polynomials exist on the word-sized classes only");
+    }
+}
+
+template <class F>
+static int monomial_compact_t(fhe_rns_ntt *h, void *out, const void *in, const uint32_t *shifts, size_t count) {
+    hipLaunchKernelGGL((fhe_dev::monomial_compact_kernel<F>), dim3(ew_grid(count)), dim3(256), 0, h->stream, (typename F::E *)out, (const typename F::E *)in, shifts,
+                       (const fhe_dev::Limb<F> *)h->d_limbs, h->L, h->log_n, count);
+    return post_launch(h->stream, "monomial_compact_kernel");
+}
+static int monomial_compact(fhe_rns_ntt *h, void *out, const void *in, const uint32_t *shifts, size_t count) {
+    switch (h->width) {
+        case FHE_WIDTH_32: return monomial_compact_t<fhe_dev::F32>(h, out, in, shifts, count);
+        case FHE_WIDTH_52: return monomial_compact_t<fhe_dev::F52>(h, out, in, shifts, count);
+        case FHE_WIDTH_64: return monomial_compact_t<fhe_dev::F64>(h, out, in, shifts, count);
+        case FHE_WIDTH_64X: return monomial_compact_t<fhe_dev::F64X>(h, out, in, shifts, count);
         default: return fail(FHE_ERR_UNSUPPORTED, "compact polynomials exist on the word-sized classes only");
     }
 }
@@ -1219,16 +1243,55 @@ extern "C" int fhe_ct_multiply_relin(fhe_rns_ntt_t *h, const fhe_relin_keys_t *r
         char *c0c = (char *)h->d_ws2, *c1c = c0c + cbytes, *c2c = c1c + cbytes;
         fhe_dev::lds_launch_fn fn = fhe_dev::lds_lookup(lds_width_id(h), (int)h->log_n);
         if (!fn) return fail(FHE_ERR_UNSUPPORTED, "transform size outside the LDS-resident range");
-        fhe_dev::LdsArgs A{fhe_dev::LDS_CT_MULTIPLY, c0c, c1c, c2c, d_a0, d_a1, d_b0, d_b1, h->d_limbs, h->L, polys, h->stream};
-        A.compact_c2 = true;
-        if ((rc = ct_workspace(h, A))) return rc;
-        fn(A);
-        if ((rc = post_launch(h->stream, "tensor product (compact outputs)"))) return rc;
-        fhe_dev::LdsArgs B{fhe_dev::LDS_KEYSWITCH, d_c0, d_c1, nullptr, c2c, c0c, c1c, nullptr, h->d_limbs, h->L, polys, h->stream};
-        B.kb = rk->d_pkb; B.ka = rk->d_pka; B.K = rk->K; B.w = rk->decomp_bits; B.compact_c2 = true;
-        B.joint3 = use_joint3(h, false, true);
-        fn(B);
-        return post_launch(h->stream, "key switch (compact operands)");
+        // The two kernels of the call sit on different roofs: the tensor product streams 4 S in at the HBM rate, the key switch (compact
+        // operands) is bound by instruction issue.  The call is therefore a two-stage pipeline over chunks of whole ciphertexts: every
+        // tensor product runs on the engine's stream, back to back; the key switch of chunk i runs on a second stream as soon as
+        // tensor product i is done (event), i.e. beside tensor product i+1 on the same CUs.  The engine's stream joins the second one
+        // at the end, so the call stays ordered on the engine's stream (and can be captured into a graph: fork / join through events).
+        // Every chunk has its own slice of the compact workspace.
+        uint32_t chunks = h->overlap_chunks;
+        char *bws = nullptr;                                     // two-launch tensor product: the transformed b-side, sized here for the whole batch, sliced per chunk
+        {
+            fhe_dev::LdsArgs probe{fhe_dev::LDS_CT_MULTIPLY, c0c, c1c, c2c, d_a0, d_a1, d_b0, d_b1, h->d_limbs, h->L, polys, h->stream};
+            probe.compact_c2 = true;
+            if ((rc = ct_workspace(h, probe))) return rc;
+            bws = (char *)probe.ws;
+            if (bws && h->log_n >= 14) chunks = 1;               // 128+ KiB of LDS per workgroup: the two stages cannot share a CU anyway
+        }
+        while (chunks > 1 && (polys / chunks < 1024 || batch < chunks)) chunks--;   // every chunk must fill the chip: >= 256 CUs x 4 workgroups (one per limb polynomial)
+        if (chunks > 1 && !h->aux_stream) {
+            HIP_TRY(hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+            for (hipEvent_t &e : h->ev_chunk) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        }
+        const size_t S = (size_t)h->L * h->n * 32, Sc = (size_t)h->L * h->n * eb;   // bytes of one ciphertext component: containers / compact
+        for (uint32_t c = 0, b0 = 0; c < chunks; c++) {
+            const uint32_t nb = batch / chunks + (c < batch % chunks ? 1 : 0);
+            const size_t o = (size_t)b0 * S, oc = (size_t)b0 * Sc;
+            fhe_dev::LdsArgs A{fhe_dev::LDS_CT_MULTIPLY, c0c + oc, c1c + oc, c2c + oc, (const char *)d_a0 + o, (const char *)d_a1 + o, (const char *)d_b0 + o,
+                               (const char *)d_b1 + o, h->d_limbs, h->L, nb * h->L, h->stream};
+            A.compact_c2 = true;
+            if (bws) A.ws = bws + 2 * oc;                        // two compact polynomials per limb polynomial of the chunk
+            fn(A);
+            if ((rc = post_launch(h->stream, "tensor product (compact outputs)"))) return rc;
+            hipStream_t ks = h->stream;
+            if (chunks > 1) {
+                HIP_TRY(hipEventRecord(h->ev_chunk[c], h->stream));
+                HIP_TRY(hipStreamWaitEvent(h->aux_stream, h->ev_chunk[c], 0));
+                ks = h->aux_stream;
+            }
+            fhe_dev::LdsArgs B{fhe_dev::LDS_KEYSWITCH, (char *)d_c0 + o, (char *)d_c1 + o, nullptr, c2c + oc, c0c + oc, c1c + oc, nullptr, h->d_limbs, h->L, nb * h->L, ks};
+            B.kb = rk->d_pkb; B.ka = rk->d_pka; B.K = rk->K; B.w = rk->decomp_bits; B.compact_c2 = true;
+            B.joint3 = use_joint3(h, false, true);
+            fn(B);
+            if ((rc = post_launch(ks, "key switch (compact operands)"))) return rc;
+            b0 += nb;
+        }
+        if (chunks > 1) {
+            HIP_TRY(hipEventRecord(h->ev_join, h->aux_stream));
+            HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_join, 0));
+        }
+        return FHE_OK;
     }
     if ((rc = ensure_ws2(h, (size_t)polys * h->n * 32))) return rc;
     if ((rc = do_ct_multiply(h, d_c0, d_c1, h->d_ws2, d_a0, d_a1, d_b0, d_b1, batch))) return rc;
@@ -1320,7 +1383,9 @@ static int to_rns_word(fhe_rns_ntt *h, void *d_rns, const void *d_values, uint32
 extern "C" int fhe_rns_to_rns(fhe_rns_ntt_t *h, void *d_rns, const void *d_values, uint32_t batch) {
     int rc = check_call(h, batch, "to_rns"); if (rc) return rc;
     if (!d_rns || !d_values || d_rns == d_values) return fail(FHE_ERR_INVALID_ARG, "to_rns: null or aliased argument");
-    if (!h->no_word_conversions) {       // word-sized classes: a streaming kernel on the field type
+    // (to_rns_word_kernel stores through lane pairs of WHOLE waves, store_wave_containers: every wave must cover 64 consecutive containers
+    //  of one polynomial, i.e. n a multiple of 256.  Word-sized classes exist from n = 2^11, the guard keeps that an explicit condition.)
+    if (!h->no_word_conversions && h->log_n >= 8) {       // word-sized classes: a streaming kernel on the field type
         if (h->width == FHE_WIDTH_32) return to_rns_word<fhe_dev::F32, uint32_t>(h, d_rns, d_values, batch);
         if (h->width == FHE_WIDTH_52) return to_rns_word<fhe_dev::F52, uint32_t>(h, d_rns, d_values, batch);
         if (h->width == FHE_WIDTH_64) return to_rns_word<fhe_dev::F64, uint64_t>(h, d_rns, d_values, batch);
@@ -1449,7 +1514,7 @@ extern "C" int fhe_rns_fast_base_convert(fhe_rns_ntt_t *h, fhe_rns_ntt_t *target
     int rc = check_call(h, batch, "fast_base_convert"); if (rc) return rc;
     if (!target || !d_out || !d_in || d_out == d_in) return fail(FHE_ERR_INVALID_ARG, "fast_base_convert: null or aliased argument");
     if (target->n != h->n) return fail(FHE_ERR_INVALID_ARG, "fast_base_convert: source and target engines differ in degree");
-    if (h->width == target->width && h->width != FHE_WIDTH_256 && !h->no_word_conversions) {
+    if (h->width == target->width && h->width != FHE_WIDTH_256 && !h->no_word_conversions && h->log_n >= 8) {   // whole waves per polynomial, as in to_rns
         if (h->width == FHE_WIDTH_32) return base_convert_word<fhe_dev::F32>(h, target, d_out, d_in, batch);
         if (h->width == FHE_WIDTH_52) return base_convert_word<fhe_dev::F52>(h, target, d_out, d_in, batch);
         if (h->width == FHE_WIDTH_64X) return base_convert_word<fhe_dev::F64X>(h, target, d_out, d_in, batch);
@@ -1511,10 +1576,11 @@ static int blind_rotate_step_general(fhe_rns_ntt_t *h, const fhe_relin_keys_t *r
 }
 // One step as ONE launch (word-sized classes with packed rows): (out0, out1) = (in0, in1) + ExtProd((X^a - 1) * in, RGSW).
 static int blind_rotate_step_fused(fhe_rns_ntt_t *h, const fhe_relin_keys_t *r0, const fhe_relin_keys_t *r1, void *out0, void *out1, const void *in0,
-                                   const void *in1, const uint32_t *d_shifts, uint32_t batch, bool in_compact = false, bool out_compact = false) {
+                                   const void *in1, const uint32_t *d_shifts, uint32_t batch, bool in_compact = false, bool out_compact = false,
+                                   const void *rot0 = nullptr, const void *rot1 = nullptr) {
     fhe_dev::lds_launch_fn fn = fhe_dev::lds_lookup(lds_width_id(h), (int)h->log_n);
     if (!fn) return fail(FHE_ERR_UNSUPPORTED, "transform size outside the LDS-resident range");
-    fhe_dev::LdsArgs A{fhe_dev::LDS_EXTPROD, out0, out1, nullptr, in0, in1, nullptr, nullptr, h->d_limbs, h->L, batch * h->L, h->stream};
+    fhe_dev::LdsArgs A{fhe_dev::LDS_EXTPROD, out0, out1, nullptr, in0, in1, rot0, rot1, h->d_limbs, h->L, batch * h->L, h->stream};   // b0, b1: pre-rotated digit sources (three-array kernel)
     A.kb = r0->d_pkb; A.ka = r0->d_pka; A.kb1 = r1->d_pkb; A.ka1 = r1->d_pka; A.K = r0->K; A.w = r0->decomp_bits; A.shifts = d_shifts;
     A.in_compact = in_compact; A.out_compact = out_compact;
     A.joint3 = use_joint3(h, true, false);
@@ -1563,6 +1629,29 @@ extern "C" int fhe_blind_rotate(fhe_rns_ntt_t *h, const fhe_relin_keys_t *const 
             const void *i0 = first ? d_acc0 : pp[(s + 1) & 1][0], *i1 = first ? d_acc1 : pp[(s + 1) & 1][1];
             void *o0 = last ? d_acc0 : pp[s & 1][0], *o1 = last ? d_acc1 : pp[s & 1][1];
             if ((rc = blind_rotate_step_fused(h, rows_c0[s], rows_c1[s], o0, o1, i0, i1, d_shifts + (size_t)s * batch, batch, !first, !last))) return rc;
+        }
+        return FHE_OK;
+    }
+    // Three-array kernel (8-byte residues; 4-byte residues at N = 2^15): every limb workgroup re-reads each limb of the accumulator pair once
+    // per DIGIT (rotated), L * K * 2 reads per workgroup -- as containers that was several times the algorithmic traffic.  The pair is
+    // compacted once (compact_kernel), every step reads compact input, all but the last write compact output (workspace ping-pong).
+    if (steps >= 1 && use_joint3(h, true, false) && !h->no_compact_blind_rotate) {
+        const size_t eb = residue_bytes(h), cbytes = (size_t)batch * h->L * h->n * eb, count = (size_t)batch * h->L * h->n;
+        if ((rc = ensure_ws2(h, 6 * cbytes))) return rc;
+        char *w0 = (char *)h->d_ws2;
+        char *pp[2][2] = {{w0, w0 + cbytes}, {w0 + 2 * cbytes, w0 + 3 * cbytes}};
+        char *rot0 = w0 + 4 * cbytes, *rot1 = w0 + 5 * cbytes;       // (X^a - 1) * acc of the current step
+        if ((rc = compact_poly(h, pp[1][0], d_acc0, count))) return rc;
+        if ((rc = compact_poly(h, pp[1][1], d_acc1, count))) return rc;
+        for (uint32_t s = 0; s < steps; s++) {
+            const bool last = s + 1 == steps;
+            const void *i0 = pp[(s + 1) & 1][0], *i1 = pp[(s + 1) & 1][1];
+            void *o0 = last ? d_acc0 : pp[s & 1][0], *o1 = last ? d_acc1 : pp[s & 1][1];
+            const uint32_t *sh = d_shifts + (size_t)s * batch;
+            // the monomial factor once per step (a streaming pass over two compact polynomials) instead of once per digit inside the kernel
+            const bool prerot = !h->no_prerotation;
+            if (prerot && ((rc = monomial_compact(h, rot0, i0, sh, count)) || (rc = monomial_compact(h, rot1, i1, sh, count)))) return rc;
+            if ((rc = blind_rotate_step_fused(h, rows_c0[s], rows_c1[s], o0, o1, i0, i1, sh, batch, true, !last, prerot ? rot0 : nullptr, prerot ? rot1 : nullptr))) return rc;
         }
         return FHE_OK;
     }

@@ -149,10 +149,18 @@ void CAT(lds_launch_, FHE_FIELD, FHE_LOGN)(const LdsArgs &A) {
             using E = typename F::E;
             if constexpr (lds_keyswitch_split(sizeof(E), LOGN)) {
                 if (A.joint3) {
-                    if constexpr (lds_keyswitch_joint3(sizeof(E), LOGN))
-                        hipLaunchKernelGGL((ntt_extprod3_kernel<F, LOGN, 2>), grid, block, 0, A.stream, (char *)A.r0, (char *)A.r1,
-                                           (const char *)A.a0, (const char *)A.a1, A.shifts, (const E *)A.kb, (const E *)A.ka, (const E *)A.kb1,
-                                           (const E *)A.ka1, limbs, A.L, A.K, A.w);
+                    if constexpr (lds_keyswitch_joint3(sizeof(E), LOGN)) {
+#define EXTPROD3(IC, OC, PR) hipLaunchKernelGGL((ntt_extprod3_kernel<F, LOGN, 2, IC, OC, PR>), grid, block, 0, A.stream, (char *)A.r0, (char *)A.r1, \
+                                       (const char *)A.a0, (const char *)A.a1, (const char *)A.b0, (const char *)A.b1, A.shifts, (const E *)A.kb, (const E *)A.ka, \
+                                       (const E *)A.kb1, (const E *)A.ka1, limbs, A.L, A.K, A.w)
+                        if (A.b0) {                           // pre-rotated digit sources (b0, b1): the loop form of fhe_blind_rotate, always compact input
+                            if (A.out_compact) EXTPROD3(true, true, true); else EXTPROD3(true, false, true);
+                        }
+                        else if (A.in_compact && A.out_compact) EXTPROD3(true, true, false);
+                        else if (A.in_compact) EXTPROD3(true, false, false);
+                        else EXTPROD3(false, false, false);   // (container input with compact output is never asked for: the host compacts first)
+#undef EXTPROD3
+                    }
                 } else
                 hipLaunchKernelGGL((ntt_extprod_kernel<F, LOGN, 2, true>), dim3(A.polys * 2), block, 0, A.stream, (char *)A.r0, (char *)A.r1,
                                    (const char *)A.a0, (const char *)A.a1, A.shifts, (const E *)A.kb, (const E *)A.ka, (const E *)A.kb1,

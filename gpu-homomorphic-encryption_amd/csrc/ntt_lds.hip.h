@@ -167,6 +167,20 @@ __device__ __forceinline__ void stage_twiddles(typename F::TW *twl, const typena
         if (idx >= 1) twl[tw_slot(LOGN, FWD, idx)] = gtw[idx];     // entry 0 is unused; pattern-A entries keep their natural slot
 }
 
+// Twiddle tables are reached through pointers stored in Limb<F> (device memory), so the compiler only knows them as GENERIC pointers
+// and emits flat_load: that bumps lgkmcnt as well as vmcnt (every wait on an LDS read then also waits for the twiddles in flight), needs
+// a 64-bit VGPR address per load and goes through the aperture check.  They are global memory: say so (global_load, SGPR base).
+template <class TW>
+__device__ __forceinline__ TW load_global(const TW *p) {
+    if constexpr (sizeof(TW) == 16) {
+        typedef uint64_t V __attribute__((ext_vector_type(2)));
+        const V v = *(const __attribute__((address_space(1))) V *)p;
+        TW r; r.x = v.x; r.y = v.y; return r;
+    } else {
+        return *(const __attribute__((address_space(1))) TW *)p;
+    }
+}
+
 // ---- register-resident butterfly stages -------------------------------------------------------------
 // Forward (Cooley-Tukey, merged psi twiddles): stage on index bit b uses twiddle tw[m + (i >> (b+1))], m = N >> (b+1).
 // Processes r-bits KHI down to KLO of pattern Pat.  Values stay in [0, 4q).
@@ -186,7 +200,8 @@ __device__ __forceinline__ void fwd_stages(typename F::E (&x)[32], uint32_t tid,
 #pragma unroll
         for (int r = 0; r < 32; r++) {
             if (r & (1 << k)) continue;
-            const typename F::TW w = p[TWL ? tw_slot_off<Pat>(r, k) : (Pat::off(r) >> (b + 1))];
+            typename F::TW w;
+            if constexpr (TWL) w = p[tw_slot_off<Pat>(r, k)]; else w = load_global(p + (Pat::off(r) >> (b + 1)));
             F::fwd_bfly(x[r], x[r | (1 << k)], w, P);
         }
     }
@@ -205,7 +220,8 @@ __device__ __forceinline__ void inv_stages(typename F::E (&x)[32], uint32_t tid,
 #pragma unroll
         for (int r = 0; r < 32; r++) {
             if (r & (1 << k)) continue;
-            const typename F::TW w = p[TWL ? tw_slot_off<Pat>(r, k) : (Pat::off(r) >> (b + 1))];
+            typename F::TW w;
+            if constexpr (TWL) w = p[tw_slot_off<Pat>(r, k)]; else w = load_global(p + (Pat::off(r) >> (b + 1)));
             F::inv_bfly(x[r], x[r | (1 << k)], w, P);
         }
     }
@@ -336,9 +352,54 @@ __device__ __forceinline__ void fwd_stages2(typename F::E (&x0)[32], typename F:
 #pragma unroll
         for (int r = 0; r < 32; r++) {
             if (r & (1 << k)) continue;
-            const typename F::TW w = p[Pat::off(r) >> (b + 1)];
+            const typename F::TW w = load_global(p + (Pat::off(r) >> (b + 1)));
             F::fwd_bfly(x0[r], x0[r | (1 << k)], w, P);
             F::fwd_bfly(x1[r], x1[r | (1 << k)], w, P);
+        }
+    }
+}
+// ---- twiddles issued one exchange ahead (paired transforms) --------------------------------------------------------------------
+// A wave of these kernels waits on vector-memory loads 0.44 of its lifetime (rocprofv3 SQ_WAIT_INST_ANY, round 3) although it issues only
+// ~440 of them: at two waves per SIMD every load that is consumed right after it is issued exposes its whole L2 latency, and the
+// per-lane twiddles of a register group cannot be issued before the barrier in front of it by the compiler (a barrier fences memory).
+// They depend on the thread index only, so the 31 (or 2^g - 1) twiddles of the NEXT register group are loaded into registers BEFORE
+// the exchange that precedes it and arrive while the exchange is in flight.  Slot of stage k (r-bit k), twiddle j = r >> (k+1):
+// (16 >> k) - 1 + j  (k = 4: slot 0; k = 3: 1, 2; k = 2: 3..6; k = 1: 7..14; k = 0: 15..30).
+template <class F, int LOGN, class Pat, int KHI, int KLO>
+__device__ __forceinline__ void preload_twiddles(typename F::TW (&w)[31], uint32_t tid, const typename F::TW *__restrict__ tw) {
+    static_assert(!Pat::TW_UNIFORM, "uniform stages take scalar loads");
+    const uint32_t base = Pat::base(tid);
+#pragma unroll
+    for (int k = KLO; k <= KHI; k++) {
+        const int b = Pat::BIT0 + k;
+        const typename F::TW *p = tw + ((1u << (LOGN - 1 - b)) + (base >> (b + 1)));
+#pragma unroll
+        for (int j = 0; j < (16 >> k); j++) w[(16 >> k) - 1 + j] = load_global(p + j);
+    }
+}
+template <class F, int KHI, int KLO>
+__device__ __forceinline__ void fwd_stages2_pre(typename F::E (&x0)[32], typename F::E (&x1)[32], const typename F::TW (&w)[31], const Limb<F> &P) {
+#pragma unroll
+    for (int k = KHI; k >= KLO; k--) {
+#pragma unroll
+        for (int r = 0; r < 32; r++) {
+            if (r & (1 << k)) continue;
+            const typename F::TW t = w[(16 >> k) - 1 + (r >> (k + 1))];
+            F::fwd_bfly(x0[r], x0[r | (1 << k)], t, P);
+            F::fwd_bfly(x1[r], x1[r | (1 << k)], t, P);
+        }
+    }
+}
+template <class F, int KLO, int KHI>
+__device__ __forceinline__ void inv_stages2_pre(typename F::E (&x0)[32], typename F::E (&x1)[32], const typename F::TW (&w)[31], const Limb<F> &P) {
+#pragma unroll
+    for (int k = KLO; k <= KHI; k++) {
+#pragma unroll
+        for (int r = 0; r < 32; r++) {
+            if (r & (1 << k)) continue;
+            const typename F::TW t = w[(16 >> k) - 1 + (r >> (k + 1))];
+            F::inv_bfly(x0[r], x0[r | (1 << k)], t, P);
+            F::inv_bfly(x1[r], x1[r | (1 << k)], t, P);
         }
     }
 }
@@ -347,6 +408,7 @@ template <class F, int LOGN, bool PRESYNC = false>
 __device__ __forceinline__ void fwd_core2(typename F::E (&x0)[32], typename F::E (&x1)[32], typename F::E *lds, uint32_t tid,
                                           const Limb<F> &P) {
     using C = NttCfg<LOGN>;
+#ifdef FHE_NO_TWIDDLE_PRELOAD     // compile-time A/B switch: the round-2 form (twiddles loaded where they are used)
     fwd_stages2<F, LOGN, PatA<LOGN>, 4, 0>(x0, x1, tid, P.tw, P);
     if constexpr (PRESYNC) __syncthreads();
     lds_put2<PatA<LOGN>>(lds, tid, x0, x1);
@@ -357,6 +419,21 @@ __device__ __forceinline__ void fwd_core2(typename F::E (&x0)[32], typename F::E
     __syncthreads();
     lds_get2<PatZ<LOGN>>(lds, tid, x0, x1);
     fwd_stages2<F, LOGN, PatZ<LOGN>, C::REM - 1, 0>(x0, x1, tid, P.tw, P);
+#else
+    typename F::TW w[31];
+    preload_twiddles<F, LOGN, PatM<LOGN>, 4, 0>(w, tid, P.tw);          // in flight under the first register group and the first exchange
+    fwd_stages2<F, LOGN, PatA<LOGN>, 4, 0>(x0, x1, tid, P.tw, P);
+    if constexpr (PRESYNC) __syncthreads();
+    lds_put2<PatA<LOGN>>(lds, tid, x0, x1);
+    __syncthreads();
+    lds_get2<PatM<LOGN>>(lds, tid, x0, x1);
+    fwd_stages2_pre<F, 4, 0>(x0, x1, w, P);
+    preload_twiddles<F, LOGN, PatZ<LOGN>, C::REM - 1, 0>(w, tid, P.tw);  // in flight under the second exchange
+    lds_put2<PatM<LOGN>>(lds, tid, x0, x1);       // same slots this thread just read: no barrier needed before
+    __syncthreads();
+    lds_get2<PatZ<LOGN>>(lds, tid, x0, x1);
+    fwd_stages2_pre<F, C::REM - 1, 0>(x0, x1, w, P);
+#endif
 }
 
 // NTT values in pattern Z, in [0, 2q)  ->  coefficients in pattern A, in [0, 2q), scaled by the (ninv..) constants
@@ -399,7 +476,7 @@ __device__ __forceinline__ void inv_stages2(typename F::E (&x0)[32], typename F:
 #pragma unroll
         for (int r = 0; r < 32; r++) {
             if (r & (1 << k)) continue;
-            const typename F::TW w = p[Pat::off(r) >> (b + 1)];
+            const typename F::TW w = load_global(p + (Pat::off(r) >> (b + 1)));
             F::inv_bfly(x0[r], x0[r | (1 << k)], w, P);
             F::inv_bfly(x1[r], x1[r | (1 << k)], w, P);
         }
@@ -409,6 +486,7 @@ template <class F, int LOGN, bool PRESYNC = false>
 __device__ __forceinline__ void inv_core2(typename F::E (&x0)[32], typename F::E (&x1)[32], typename F::E *lds, uint32_t tid,
                                           const Limb<F> &P, typename F::E ninv, typename F::E ninv_s, typename F::E ninvw, typename F::E ninvw_s) {
     using C = NttCfg<LOGN>;
+#ifdef FHE_NO_TWIDDLE_PRELOAD
     inv_stages2<F, LOGN, PatZ<LOGN>, 0, 4>(x0, x1, tid, P.itw, P);
     F::regroup(x0, P.q, P.qinv); F::regroup(x1, P.q, P.qinv);
     if constexpr (PRESYNC) __syncthreads();
@@ -416,6 +494,18 @@ __device__ __forceinline__ void inv_core2(typename F::E (&x0)[32], typename F::E
     __syncthreads();
     lds_get2<PatY<LOGN>>(lds, tid, x0, x1);
     inv_stages2<F, LOGN, PatY<LOGN>, 0, 4>(x0, x1, tid, P.itw, P);
+#else
+    typename F::TW w[31];
+    preload_twiddles<F, LOGN, PatZ<LOGN>, 4, 0>(w, tid, P.itw);          // needed at once (issued together: one latency, not five)
+    inv_stages2_pre<F, 0, 4>(x0, x1, w, P);
+    F::regroup(x0, P.q, P.qinv); F::regroup(x1, P.q, P.qinv);
+    preload_twiddles<F, LOGN, PatY<LOGN>, 4, 0>(w, tid, P.itw);          // in flight under the first exchange
+    if constexpr (PRESYNC) __syncthreads();
+    lds_put2<PatZ<LOGN>>(lds, tid, x0, x1);
+    __syncthreads();
+    lds_get2<PatY<LOGN>>(lds, tid, x0, x1);
+    inv_stages2_pre<F, 0, 4>(x0, x1, w, P);
+#endif
     F::regroup(x0, P.q, P.qinv); F::regroup(x1, P.q, P.qinv);
     lds_put2<PatY<LOGN>>(lds, tid, x0, x1);
     __syncthreads();
@@ -1197,10 +1287,13 @@ ntt_extprod_kernel(char *__restrict__ out0, char *__restrict__ out1, const char 
 
 // External product for the 8-byte residues at N = 2^14 in ONE workgroup per (accumulator, limb) with three live arrays (both output
 // accumulators and the digit polynomial; the input limb is re-read, rotated, for every digit) -- the counterpart of
-// ntt_keyswitch3_kernel: half the transforms of the SPLIT form above.
-template <class F, int LOGN, int MINW = 1>
+// ntt_keyswitch3_kernel: half the transforms of the SPLIT form above.  IN_COMPACT / OUT_COMPACT as in ntt_extprod2_kernel: inside fhe_blind_rotate
+// the accumulator pair is compacted once (compact_kernel) and stays compact between the steps, so the L * K rotated re-reads of a limb per
+// workgroup move 8 instead of 32 bytes per coefficient.
+template <class F, int LOGN, int MINW = 1, bool IN_COMPACT = false, bool OUT_COMPACT = false, bool PREROT = false>
 __global__ void __launch_bounds__(NttCfg<LOGN>::T, MINW)
 ntt_extprod3_kernel(char *__restrict__ out0, char *__restrict__ out1, const char *__restrict__ in0, const char *__restrict__ in1,
+                    const char *__restrict__ rot0, const char *__restrict__ rot1,     // PREROT: (X^a - 1) * in, compact (monomial_compact_kernel); else unused
                     const uint32_t *__restrict__ shifts,
                     const typename F::E *__restrict__ kb0, const typename F::E *__restrict__ ka0,
                     const typename F::E *__restrict__ kb1, const typename F::E *__restrict__ ka1,
@@ -1208,6 +1301,7 @@ ntt_extprod3_kernel(char *__restrict__ out0, char *__restrict__ out1, const char
     using C = NttCfg<LOGN>;
     using E = typename F::E;
     constexpr int VPL = 16 / sizeof(E), NCH = 32 / VPL;
+    constexpr size_t IN_POLY = C::N * (IN_COMPACT ? sizeof(E) : 32);        // bytes of one input polynomial
     typedef E VecE __attribute__((ext_vector_type(VPL)));
     __shared__ E lds[C::LDS_ELEMS];
     const uint32_t tid = threadIdx.x, bid = blockIdx.x, full = (gridDim.x / (8 * L)) * (8 * L);
@@ -1222,12 +1316,15 @@ ntt_extprod3_kernel(char *__restrict__ out0, char *__restrict__ out1, const char
     for (int r = 0; r < 32; r++) { acc0[r] = 0; acc1[r] = 0; }
     const uint32_t voff = tid * 16;
     for (uint32_t c = 0; c < 2; c++) {
-        const TableBuf KB(c ? kb1 : kb0), KA(c ? ka1 : ka0), SRC((c ? in1 : in0) + (size_t)b * L * (C::N * 32));   // this accumulator's component c
+        const TableBuf KB(c ? kb1 : kb0), KA(c ? ka1 : ka0),
+                       SRC(PREROT ? (c ? rot1 : rot0) + (size_t)b * L * (C::N * sizeof(E)) : (c ? in1 : in0) + (size_t)b * L * IN_POLY);   // this accumulator's component c
         for (uint32_t j = 0; j < L; j++) {
             const E qj = limbs[j].q;
             for (uint32_t k = 0; k < K; k++) {
-                if constexpr (__is_same(typename F::E, double)) load_monomial_A<F, LOGN>(c ? in1 : in0, (size_t)b * L + j, lds, tid, a, qj, d);
-                else load_monomial_A_buf<F, LOGN>(SRC, j, lds, tid, a, qj, d);
+                // (the FP64 field keeps flat loads here: descriptor loads of the rotated limb measured 12-17 % slower on it, round 2)
+                if constexpr (PREROT) load_src_buf<F, LOGN, true>(SRC, j, tid, d);       // already rotated: a plain compact load, no exchange-buffer round trip
+                else if constexpr (__is_same(typename F::E, double)) load_monomial_A<F, LOGN, IN_COMPACT>(c ? in1 : in0, (size_t)b * L + j, lds, tid, a, qj, d);
+                else load_monomial_A_buf<F, LOGN, IN_COMPACT>(SRC, j, lds, tid, a, qj, d);
 #pragma unroll
                 for (int r = 0; r < 32; r++) d[r] = F::digit(d[r], k * w, w);
                 fwd_core<F, LOGN, false, true>(d, lds, tid, P);
@@ -1251,21 +1348,29 @@ ntt_extprod3_kernel(char *__restrict__ out0, char *__restrict__ out1, const char
     }
     inv_core<F, LOGN, false, true>(acc0, lds, tid, P, P.ninv, P.ninv_s, P.ninvw, P.ninvw_s);
     __builtin_amdgcn_sched_barrier(0);
-    load_poly_buf<F, LOGN, false>(in0 + (size_t)p * (C::N * 32), tid, d);
+    load_poly_buf<F, LOGN, IN_COMPACT>(in0 + (size_t)p * IN_POLY, tid, d);
 #pragma unroll
     for (int r = 0; r < 32; r++) acc0[r] = F::ew_add(F::canon_inv(acc0[r], P.q), d[r], P.q);
-    lds_put<PatA<LOGN>>(lds, tid, acc0);
-    __syncthreads();
-    store_from_lds_rolled<F, LOGN>(out0 + (size_t)p * (C::N * 32), lds, tid);
+    if constexpr (OUT_COMPACT) {
+        store_A_compact<F, LOGN>(reinterpret_cast<E *>(out0) + (size_t)p * C::N, tid, acc0);
+    } else {
+        lds_put<PatA<LOGN>>(lds, tid, acc0);
+        __syncthreads();
+        store_from_lds_rolled<F, LOGN>(out0 + (size_t)p * (C::N * 32), lds, tid);
+    }
     __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
     inv_core<F, LOGN>(acc1, lds, tid, P, P.ninv, P.ninv_s, P.ninvw, P.ninvw_s);
-    load_poly_buf<F, LOGN, false>(in1 + (size_t)p * (C::N * 32), tid, d);
+    load_poly_buf<F, LOGN, IN_COMPACT>(in1 + (size_t)p * IN_POLY, tid, d);
 #pragma unroll
     for (int r = 0; r < 32; r++) acc1[r] = F::ew_add(F::canon_inv(acc1[r], P.q), d[r], P.q);
-    lds_put<PatA<LOGN>>(lds, tid, acc1);
-    __syncthreads();
-    store_from_lds<F, LOGN>(out1 + (size_t)p * (C::N * 32), lds, tid);
+    if constexpr (OUT_COMPACT) {
+        store_A_compact<F, LOGN>(reinterpret_cast<E *>(out1) + (size_t)p * C::N, tid, acc1);
+    } else {
+        lds_put<PatA<LOGN>>(lds, tid, acc1);
+        __syncthreads();
+        store_from_lds<F, LOGN>(out1 + (size_t)p * (C::N * 32), lds, tid);
+    }
 }
 
 // ---- paired forms of the key-switch and external-product kernels (4-byte residues) --------------------------------------
@@ -1293,7 +1398,10 @@ __device__ __forceinline__ void mac_keys(typename F::E (&acc0)[32], typename F::
     }
 }
 // acc0 += kb[t0] .* d0 + kb[t1] .* d1, acc1 likewise with ka: the two products of a pair share one Montgomery reduction (mont_mul2)
-template <class F>
+// PIPE: the four 16-byte key loads of chunk c+1 are issued BEFORE the products of chunk c (explicit double buffer, pinned by scheduling
+// fences): without it every chunk's loads are consumed right after they are issued and a wave exposes the L2 latency eight times per
+// digit pair (the compiler's own schedule keeps at most ~1.5 chunks in flight); 16 more VGPRs.
+template <class F, bool PIPE = false>
 __device__ __forceinline__ void mac_keys2(typename F::E (&acc0)[32], typename F::E (&acc1)[32], const typename F::E (&d0)[32], const typename F::E (&d1)[32],
                                           const typename F::E *__restrict__ kb0, const typename F::E *__restrict__ ka0, size_t tbl0,
                                           const typename F::E *__restrict__ kb1, const typename F::E *__restrict__ ka1, size_t tbl1,
@@ -1304,15 +1412,37 @@ __device__ __forceinline__ void mac_keys2(typename F::E (&acc0)[32], typename F:
     typedef E VecE __attribute__((ext_vector_type(VPL)));
     const TableBuf KB0(kb0), KA0(ka0), KB1(kb1), KA1(ka1);
     const uint32_t voff = tid * 16, row0 = (uint32_t)(tbl0 * sizeof(E)), row1 = (uint32_t)(tbl1 * sizeof(E));
+    if constexpr (PIPE) {
+        VecE vb0[2], va0[2], vb1[2], va1[2];
+        vb0[0] = KB0.template load16<VecE>(voff, row0); va0[0] = KA0.template load16<VecE>(voff, row0);
+        vb1[0] = KB1.template load16<VecE>(voff, row1); va1[0] = KA1.template load16<VecE>(voff, row1);
 #pragma unroll
-    for (int c = 0; c < NCH; c++) {
-        const VecE vb0 = KB0.template load16<VecE>(voff, row0 + c * T * 16), va0 = KA0.template load16<VecE>(voff, row0 + c * T * 16);
-        const VecE vb1 = KB1.template load16<VecE>(voff, row1 + c * T * 16), va1 = KA1.template load16<VecE>(voff, row1 + c * T * 16);
+        for (int c = 0; c < NCH; c++) {
+            const int cur = c & 1, nxt = cur ^ 1;
+            if (c + 1 < NCH) {
+                vb0[nxt] = KB0.template load16<VecE>(voff, row0 + (c + 1) * T * 16); va0[nxt] = KA0.template load16<VecE>(voff, row0 + (c + 1) * T * 16);
+                vb1[nxt] = KB1.template load16<VecE>(voff, row1 + (c + 1) * T * 16); va1[nxt] = KA1.template load16<VecE>(voff, row1 + (c + 1) * T * 16);
+            }
+            __builtin_amdgcn_sched_barrier(0);          // the next chunk's loads stay above this chunk's products
 #pragma unroll
-        for (int e = 0; e < VPL; e++) {
-            const int r = c * VPL + e;
-            acc0[r] = F::pw_add(acc0[r], F::mont_mul2(vb0[e], d0[r], vb1[e], d1[r], P.q, P.q2, P.qinv), P.q, P.q2);
-            acc1[r] = F::pw_add(acc1[r], F::mont_mul2(va0[e], d0[r], va1[e], d1[r], P.q, P.q2, P.qinv), P.q, P.q2);
+            for (int e = 0; e < VPL; e++) {
+                const int r = c * VPL + e;
+                acc0[r] = F::pw_add(acc0[r], F::mont_mul2(vb0[cur][e], d0[r], vb1[cur][e], d1[r], P.q, P.q2, P.qinv), P.q, P.q2);
+                acc1[r] = F::pw_add(acc1[r], F::mont_mul2(va0[cur][e], d0[r], va1[cur][e], d1[r], P.q, P.q2, P.qinv), P.q, P.q2);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < NCH; c++) {
+            const VecE vb0 = KB0.template load16<VecE>(voff, row0 + c * T * 16), va0 = KA0.template load16<VecE>(voff, row0 + c * T * 16);
+            const VecE vb1 = KB1.template load16<VecE>(voff, row1 + c * T * 16), va1 = KA1.template load16<VecE>(voff, row1 + c * T * 16);
+#pragma unroll
+            for (int e = 0; e < VPL; e++) {
+                const int r = c * VPL + e;
+                acc0[r] = F::pw_add(acc0[r], F::mont_mul2(vb0[e], d0[r], vb1[e], d1[r], P.q, P.q2, P.qinv), P.q, P.q2);
+                acc1[r] = F::pw_add(acc1[r], F::mont_mul2(va0[e], d0[r], va1[e], d1[r], P.q, P.q2, P.qinv), P.q, P.q2);
+            }
         }
     }
 }
@@ -1366,21 +1496,32 @@ ntt_keyswitch2_kernel(char *c0, char *c1, const char *__restrict__ c2, const cha
     for (int r = 0; r < 32; r++) { acc0[r] = 0; acc1[r] = 0; }
     const uint32_t LK = L * K;
     uint32_t jk = 0;
+    // PREFETCH (N <= 2^13; at 2^14 the 32 extra registers spill): the source limb of the NEXT pair is loaded before the key products of
+    // the current one (nx), so its HBM / L2 latency hides under the multiply-accumulate phase instead of being exposed at the top of
+    // every iteration.
+    constexpr bool PREFETCH = LOGN <= 13;
+    E nx[32];
+    if (PREFETCH && LK >= 2) load_src_buf<F, LOGN, COMPACT>(C2, 1 / K, tid, nx);
     for (; jk + 1 < LK; jk += 2) {
         const uint32_t j0 = jk / K, k0 = jk % K, j1 = (jk + 1) / K, k1 = (jk + 1) % K;
-        load_src_buf<F, LOGN, COMPACT>(C2, j1, tid, d1);
+        if constexpr (!PREFETCH) load_src_buf<F, LOGN, COMPACT>(C2, j1, tid, nx);
         if (j0 == j1) {
 #pragma unroll
-            for (int r = 0; r < 32; r++) d0[r] = F::digit(d1[r], k0 * w, w);
+            for (int r = 0; r < 32; r++) d0[r] = F::digit(nx[r], k0 * w, w);
         } else {
             load_src_buf<F, LOGN, COMPACT>(C2, j0, tid, d0);
 #pragma unroll
             for (int r = 0; r < 32; r++) d0[r] = F::digit(d0[r], k0 * w, w);
         }
 #pragma unroll
-        for (int r = 0; r < 32; r++) d1[r] = F::digit(d1[r], k1 * w, w);
+        for (int r = 0; r < 32; r++) d1[r] = F::digit(nx[r], k1 * w, w);
         fwd_core2<F, LOGN, true>(d0, d1, lds, tid, P);
-        mac_keys2<F>(acc0, acc1, d0, d1, kb, ka, ((size_t)jk * L + i) * C::N, kb, ka, ((size_t)(jk + 1) * L + i) * C::N, tid, C::T, P);
+        if constexpr (PREFETCH) {
+            __builtin_amdgcn_sched_barrier(0);           // not earlier: 32 more live registers inside the transform would spill
+            if (jk + 3 < LK) load_src_buf<F, LOGN, COMPACT>(C2, (jk + 3) / K, tid, nx);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        mac_keys2<F, true>(acc0, acc1, d0, d1, kb, ka, ((size_t)jk * L + i) * C::N, kb, ka, ((size_t)(jk + 1) * L + i) * C::N, tid, C::T, P);
     }
     if (jk < LK) {                                        // odd number of digit polynomials: the last one alone
         const uint32_t j0 = jk / K, k0 = jk % K;

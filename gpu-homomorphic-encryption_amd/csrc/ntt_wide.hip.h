@@ -116,8 +116,11 @@ template <int NL> __device__ __forceinline__ void wstore_c(u256 *p, const wint<N
     if constexpr (NL == 4) { v4u32w hi = {x.w[4], x.w[5], x.w[6], x.w[7]}; v[1] = hi; }
     else { v4u32w z = {0u, 0u, 0u, 0u}; v[1] = z; }
 }
-template <int NL> __device__ __forceinline__ wint<NL> wload_t(const wint<NL> *p) {      // table entry (16-byte aligned)
-    const v4u32w *v = reinterpret_cast<const v4u32w *>(p);
+// Table entry (16-byte aligned).  The table pointers live in WLimb (device memory), so the compiler only knows them as generic pointers
+// and would emit flat_load (lgkmcnt + vmcnt, 64-bit VGPR address, aperture check); they are global memory: say so (as load_global does
+// for the word-sized fields, where the same change was worth +8 ... +45 % on the key-switch kernels of the 8-byte fields).
+template <int NL> __device__ __forceinline__ wint<NL> wload_t(const wint<NL> *p) {
+    const __attribute__((address_space(1))) v4u32w *v = (const __attribute__((address_space(1))) v4u32w *)p;
     wint<NL> r;
 #pragma unroll
     for (int i = 0; i < NL / 2; i++) { const v4u32w t = v[i]; r.w[4 * i] = t.x; r.w[4 * i + 1] = t.y; r.w[4 * i + 2] = t.z; r.w[4 * i + 3] = t.w; }

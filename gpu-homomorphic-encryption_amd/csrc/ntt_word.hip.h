@@ -35,6 +35,29 @@ compact_kernel(typename F::E *__restrict__ out, const typename F::V16 *__restric
     for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < containers; g += stride) out[g] = F::load_low(in + 2 * g);
 }
 
+// (X^shift[b] - 1) * in[b][l] on COMPACT polynomials (one lane per coefficient): the blind-rotation loop of the three-array kernels
+// applies the monomial ONCE per step here instead of once per digit inside the kernel (there it costs a store / barrier / rotated
+// read-back round trip through the exchange buffer and three barriers for each of the 2 * L * K digit polynomials of a workgroup).
+template <class F>
+__global__ void __launch_bounds__(256)
+monomial_compact_kernel(typename F::E *__restrict__ out, const typename F::E *__restrict__ in, const uint32_t *__restrict__ shifts,
+                        const Limb<F> *__restrict__ limbs, uint32_t L, uint32_t log_n, size_t count) {
+    using E = typename F::E;
+    const uint32_t n = 1u << log_n;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < count; g += stride) {
+        const size_t poly = g >> log_n;                                   // b * L + l
+        const uint32_t x = (uint32_t)(g & (n - 1));
+        const uint32_t a = shifts[poly / L] & (2 * n - 1);
+        uint32_t k = (x + 2 * n - a) & (2 * n - 1);
+        const bool neg = k >= n; k &= n - 1;
+        const E q = limbs[(uint32_t)(poly % L)].q;
+        E v = in[(poly << log_n) + k];
+        if (neg) v = F::ew_sub((E)0, v, q);
+        out[g] = F::ew_sub(v, in[g], q);
+    }
+}
+
 // Canonical-input scan: flags any container whose value is >= q or whose upper words are not zero.
 template <class F>
 __global__ void __launch_bounds__(256)

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Where do the waves of a kernel wait?  Four --pmc passes (VALU / LDS / vector memory / instruction cache) over one bench.py workload.
+# Where do the waves of a kernel wait?  Five --pmc passes (VALU / LDS / vector memory / instruction cache) over one bench.py workload.
 # usage: scripts/profile_sq3.sh <tag> <bench args...>     -> gpurun_out/<tag>/sq3_summary.txt
 set -u
 TAG=$1; shift
@@ -9,11 +9,12 @@ OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"; export TMPDIR=/tmp; cd "$ROOT"
 B="python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --no-verify $ARGS"
 P1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES"
-P2="SQ_WAVE_CYCLES SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT"
-P3="SQ_WAVE_CYCLES SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VMEM SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC"
-P4="SQ_WAVE_CYCLES SQ_IFETCH SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS"
+P2="SQ_WAVE_CYCLES SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_LDS_CMD_FIFO_FULL"
+P3="SQ_WAVE_CYCLES SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_VMEM_WR SQ_INSTS_SALU SQ_INSTS_SMEM"
+P4="SQ_WAVE_CYCLES SQ_IFETCH SQ_IFETCH_LEVEL SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS"
+P5="SQ_WAVE_CYCLES SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_FLAT SQ_INST_CYCLES_SMEM SQ_INST_LEVEL_SMEM SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL"
 i=0
-for P in "$P1" "$P2" "$P3" "$P4"; do i=$((i+1))
+for P in "$P1" "$P2" "$P3" "$P4" "$P5"; do i=$((i+1))
   rocprofv3 --pmc $P --output-format csv -d "$OUT/sq3_$i" -- $B > "$OUT/sq3_$i.log" 2>&1 || echo "pass $i failed (see $OUT/sq3_$i.log)"
 done
 python3 - "$OUT" <<'PY' | tee "$OUT/sq3_summary.txt"

@@ -764,7 +764,7 @@ def test_blind_rotate_step_matches_oracle(eng, oracle, n, spec, w, batch):
                                                   (32768, ("bits", 30, 2), 16, 2, 2), (4096, ("bits", 40, 2), 20, 3, 3), (2048, ("bits", 60, 2), 32, 2, 2),
                                                   (256, ("bits", 250, 1), 64, 2, 2), (2048, ("bits", 64, 2), 32, 2, 3),
                                                   (16384, ("bits", 40, 2), 20, 2, 2), (16384, ("bits", 60, 1), 32, 1, 3)])      # three-array / split kernels
-@pytest.mark.parametrize("fused", [True, False, "single", "containers", "split"])
+@pytest.mark.parametrize("fused", [True, False, "single", "containers", "split", "no-prerotation"])
 def test_blind_rotate_loop_matches_oracle(eng, oracle, monkeypatch, n, spec, w, batch, steps, fused):
     """fhe_blind_rotate: `steps` external products with a different RGSW row set and different shifts per step; the fused
     one-launch-per-step path (ping-pong buffers, odd and even step counts; digit transforms two at a time -- the default where
@@ -777,6 +777,8 @@ def test_blind_rotate_loop_matches_oracle(eng, oracle, monkeypatch, n, spec, w, 
         monkeypatch.setenv("FHE_HIP_SPLIT_KEYSWITCH", "1")
     elif fused == "containers":     # fused steps, accumulators ping-pong through the caller's container buffers instead of the compact workspace
         monkeypatch.setenv("FHE_HIP_NO_COMPACT_BLIND_ROTATE", "1")
+    elif fused == "no-prerotation":  # three-array kernels: the monomial factor applied per digit inside the kernel instead of once per step by monomial_compact_kernel
+        monkeypatch.setenv("FHE_HIP_NO_PREROTATION", "1")
     moduli = _moduli(spec, n); L = len(moduli)
     e = eng.RnsNttEngine(n, moduli); rp = oracle.RnsPlan(n, moduli)
     K = e.relin_num_digits(w)
@@ -1104,6 +1106,16 @@ def test_bit_reverse_permutation_and_natural_order_transform(eng, oracle):
     e.forward(d); eng.bit_reverse(d, n); eng.capi.sync()
     psi = nm.find_psi(n, q)
     assert oracle.from_limbs(d.download((n, 4))) == [sum(xs[j] * pow(psi, (2 * k + 1) * j, q) for j in range(n)) % q for k in range(n)]
+
+
+def test_small_and_degree_one_engines_stay_on_the_container_class(eng):
+    """The word-sized conversion kernels store through lane pairs of whole waves (store_wave_containers): they require n to be a multiple
+    of 256, which holds because word-sized classes exist from n = 2^11 only.  Pin that: small rings and degree-1 bases of word-sized
+    primes take the 256-bit container class (and the host guards the kernels with log2 n >= 8 besides)."""
+    for n in (8, 64, 256, 1024):
+        assert eng.RnsNttEngine(n, _moduli(("bits", 30, 2), n)).width_class == eng.WIDTH_256
+    assert eng.RnsNttEngine(None, [12289, 40961]).width_class == eng.WIDTH_256          # degree-1 base of small primes
+    assert eng.RnsNttEngine(2048, _moduli(("bits", 30, 2), 2048)).width_class == eng.WIDTH_32
 
 
 def test_rns_base_without_a_ring(eng, oracle):
