@@ -336,12 +336,13 @@ def pmc_traffic(kernels, width_class, op, n, limbs, bits, batch):
             if (cfg.get("op", "multiply"), cfg.get("n"), cfg.get("limbs"), cfg.get("prime_bits"), cfg.get("batch_per_gpu")) != (op, n, limbs, bits, batch):
                 continue
             total, names = 0.0, []
-            for w in want:
-                hits = [(name, k) for name, k in d["kernels"].items() if w in name and "hbm_bytes_per_launch" in k]
-                if len(hits) != 1:
-                    raise LookupError(f"{w}: {len(hits)} entries")
-                total += hits[0][1]["hbm_bytes_per_launch"] * hits[0][1].get("launches_per_step", 1)
-                names.append(hits[0][0].split("(")[0])
+            for w in want:                       # every template instance of the kernel this step launches (e.g. the compact-in / compact-out forms of a loop)
+                hits = [(name, k) for name, k in d["kernels"].items() if w in name and ("hbm_bytes_per_step" in k or "hbm_bytes_per_launch" in k)]
+                if not hits:
+                    raise LookupError(w)
+                for name, k in hits:             # per STEP where the summary has it (a step may launch a kernel several times); older summaries: one launch per step
+                    total += k.get("hbm_bytes_per_step", k.get("hbm_bytes_per_launch"))
+                    names.append(name.split("(")[0])
             best = {"bytes": total, "source": os.path.basename(f), "kernels": names}
         except Exception:
             continue

@@ -1615,20 +1615,23 @@ extern "C" int fhe_blind_rotate(fhe_rns_ntt_t *h, const fhe_relin_keys_t *const 
             if ((rc = blind_rotate_step_general(h, rows_c0[s], rows_c1[s], d_acc0, d_acc1, d_shifts + (size_t)s * batch, d_tmp0, d_tmp1, batch))) return rc;
         return FHE_OK;
     }
-    // Paired kernel (4-byte residues up to N = 2^14), two or more steps: the accumulator pair lives in COMPACT form between the first and
-    // the last step (workspace ping-pong, 4 bytes per coefficient): the first step reads the caller's containers, the last one writes
-    // them, and every step in between moves S/8-sized polynomials -- the L limb workgroups of an accumulator each read all of it, which
-    // in container form is 3x the algorithmic traffic (profiles/r02_blindrotate_*).  The caller's scratch pair is not touched.
-    if (steps >= 2 && h->width == FHE_WIDTH_32 && !h->single_transforms && !h->no_compact_blind_rotate && fhe_dev::lds_paired_extprod(4, (int)h->log_n)) {
-        const size_t cbytes = (size_t)batch * h->L * h->n * 4;
+    // Paired kernel (4-byte residues up to N = 2^14): the accumulator pair lives in COMPACT form for the whole call (workspace ping-pong, 4
+    // bytes per coefficient): the L limb workgroups of an accumulator each read all of it, which in container form is 3x the algorithmic
+    // traffic (profiles/r02_blindrotate_*) and made the first step of a loop 40 % slower than the others (1114 vs 785 us at N = 16384 x 6,
+    // profiles/r03_blindrotate_n16384_summary.txt).  Since round 3 the pair is compacted first (one streaming pass), every step reads compact
+    // input, the last one writes the caller's containers.  The caller's scratch pair is not touched.
+    if (steps >= 1 && h->width == FHE_WIDTH_32 && !h->single_transforms && !h->no_compact_blind_rotate && fhe_dev::lds_paired_extprod(4, (int)h->log_n)) {
+        const size_t cbytes = (size_t)batch * h->L * h->n * 4, count = (size_t)batch * h->L * h->n;
         if ((rc = ensure_ws2(h, 4 * cbytes))) return rc;
         char *w0 = (char *)h->d_ws2;
         char *pp[2][2] = {{w0, w0 + cbytes}, {w0 + 2 * cbytes, w0 + 3 * cbytes}};
+        if ((rc = compact_poly(h, pp[1][0], d_acc0, count))) return rc;
+        if ((rc = compact_poly(h, pp[1][1], d_acc1, count))) return rc;
         for (uint32_t s = 0; s < steps; s++) {
-            const bool first = s == 0, last = s + 1 == steps;
-            const void *i0 = first ? d_acc0 : pp[(s + 1) & 1][0], *i1 = first ? d_acc1 : pp[(s + 1) & 1][1];
+            const bool last = s + 1 == steps;
+            const void *i0 = pp[(s + 1) & 1][0], *i1 = pp[(s + 1) & 1][1];
             void *o0 = last ? d_acc0 : pp[s & 1][0], *o1 = last ? d_acc1 : pp[s & 1][1];
-            if ((rc = blind_rotate_step_fused(h, rows_c0[s], rows_c1[s], o0, o1, i0, i1, d_shifts + (size_t)s * batch, batch, !first, !last))) return rc;
+            if ((rc = blind_rotate_step_fused(h, rows_c0[s], rows_c1[s], o0, o1, i0, i1, d_shifts + (size_t)s * batch, batch, true, !last))) return rc;
         }
         return FHE_OK;
     }

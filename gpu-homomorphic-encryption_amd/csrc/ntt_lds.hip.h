@@ -172,6 +172,9 @@ __device__ __forceinline__ void stage_twiddles(typename F::TW *twl, const typena
 // a 64-bit VGPR address per load and goes through the aperture check.  They are global memory: say so (global_load, SGPR base).
 template <class TW>
 __device__ __forceinline__ TW load_global(const TW *p) {
+#ifdef FHE_FLAT_TWIDDLES      // compile-time A/B switch: generic-pointer loads as in rounds 1-2
+    return *p;
+#endif
     if constexpr (sizeof(TW) == 16) {
         typedef uint64_t V __attribute__((ext_vector_type(2)));
         const V v = *(const __attribute__((address_space(1))) V *)p;
@@ -188,7 +191,7 @@ __device__ __forceinline__ TW load_global(const TW *p) {
 // SUB: the 2^LOGN coefficients are block number (pre - 2^k) of a larger transform of 2^(LOGN + k) coefficients whose top k stages
 // ran elsewhere (word_pass_kernel); the stage on local bit b then uses the big table at (pre << (LOGN-1-b)) + (i >> (b+1)), which for
 // pre = 1 is the whole-transform formula.
-template <class F, int LOGN, class Pat, int KHI, int KLO, bool TWL = false, bool SUB = false>
+template <class F, int LOGN, class Pat, int KHI, int KLO, bool TWL = false, bool SUB = false, bool GTW = true>
 __device__ __forceinline__ void fwd_stages(typename F::E (&x)[32], uint32_t tid, const typename F::TW *__restrict__ tw, const Limb<F> &P, uint32_t pre = 1) {
     static_assert(!(TWL && Pat::TW_UNIFORM), "uniform stages read device memory");
     static_assert(!(TWL && SUB), "sub-transforms read their twiddles from device memory");
@@ -201,14 +204,16 @@ __device__ __forceinline__ void fwd_stages(typename F::E (&x)[32], uint32_t tid,
         for (int r = 0; r < 32; r++) {
             if (r & (1 << k)) continue;
             typename F::TW w;
-            if constexpr (TWL) w = p[tw_slot_off<Pat>(r, k)]; else w = load_global(p + (Pat::off(r) >> (b + 1)));
+            if constexpr (TWL) w = p[tw_slot_off<Pat>(r, k)];
+            else if constexpr (GTW) w = load_global(p + (Pat::off(r) >> (b + 1)));
+            else w = p[Pat::off(r) >> (b + 1)];
             F::fwd_bfly(x[r], x[r | (1 << k)], w, P);
         }
     }
 }
 // Inverse (Gentleman-Sande): stage on index bit b uses itw[m + (i >> (b+1))].  Processes r-bits KLO up to KHI.
 // Values stay in [0, 2q).
-template <class F, int LOGN, class Pat, int KLO, int KHI, bool TWL = false, bool SUB = false>
+template <class F, int LOGN, class Pat, int KLO, int KHI, bool TWL = false, bool SUB = false, bool GTW = true>
 __device__ __forceinline__ void inv_stages(typename F::E (&x)[32], uint32_t tid, const typename F::TW *__restrict__ itw, const Limb<F> &P, uint32_t pre = 1) {
     static_assert(!(TWL && Pat::TW_UNIFORM), "uniform stages read device memory");
     static_assert(!(TWL && SUB), "sub-transforms read their twiddles from device memory");
@@ -221,7 +226,9 @@ __device__ __forceinline__ void inv_stages(typename F::E (&x)[32], uint32_t tid,
         for (int r = 0; r < 32; r++) {
             if (r & (1 << k)) continue;
             typename F::TW w;
-            if constexpr (TWL) w = p[tw_slot_off<Pat>(r, k)]; else w = load_global(p + (Pat::off(r) >> (b + 1)));
+            if constexpr (TWL) w = p[tw_slot_off<Pat>(r, k)];
+            else if constexpr (GTW) w = load_global(p + (Pat::off(r) >> (b + 1)));
+            else w = p[Pat::off(r) >> (b + 1)];
             F::inv_bfly(x[r], x[r | (1 << k)], w, P);
         }
     }
@@ -320,21 +327,21 @@ __device__ __forceinline__ void store_from_lds_rolled(char *__restrict__ poly, c
 // PRESYNC: the barrier that protects the exchange buffer from the PREVIOUS transform's last reads sits here, after the
 // register-only first group, instead of at the end of the caller's loop body: the latest legal place, where it coincides with
 // the transform's own first barrier (a wave that is ahead keeps computing instead of waiting early).
-template <class F, int LOGN, bool TWL = false, bool PRESYNC = false, bool SUB = false>
+template <class F, int LOGN, bool TWL = false, bool PRESYNC = false, bool SUB = false, bool GTW = true>
 __device__ __forceinline__ void fwd_core(typename F::E (&x)[32], typename F::E *lds, uint32_t tid, const Limb<F> &P,
                                          const typename F::TW *twl = nullptr, uint32_t pre = 1) {
     using C = NttCfg<LOGN>;
     const typename F::TW *t2 = TWL ? twl : P.tw;
-    fwd_stages<F, LOGN, PatA<LOGN>, 4, 0, false, SUB>(x, tid, P.tw, P, pre);
+    fwd_stages<F, LOGN, PatA<LOGN>, 4, 0, false, SUB, GTW>(x, tid, P.tw, P, pre);
     if constexpr (PRESYNC) __syncthreads();
     lds_put<PatA<LOGN>>(lds, tid, x);
     __syncthreads();
     lds_get<PatM<LOGN>>(lds, tid, x);
-    fwd_stages<F, LOGN, PatM<LOGN>, 4, 0, TWL, SUB>(x, tid, t2, P, pre);
+    fwd_stages<F, LOGN, PatM<LOGN>, 4, 0, TWL, SUB, GTW>(x, tid, t2, P, pre);
     lds_put<PatM<LOGN>>(lds, tid, x);          // same slots this thread just read: no barrier needed before
     __syncthreads();
     lds_get<PatZ<LOGN>>(lds, tid, x);
-    fwd_stages<F, LOGN, PatZ<LOGN>, C::REM - 1, 0, TWL, SUB>(x, tid, t2, P, pre);
+    fwd_stages<F, LOGN, PatZ<LOGN>, C::REM - 1, 0, TWL, SUB, GTW>(x, tid, t2, P, pre);
 }
 // ---- two forward transforms under ONE modulus at once ------------------------------------------------------------------
 // The key-switch and external-product kernels transform many digit polynomials under the same modulus.  Doing two of them
@@ -403,6 +410,66 @@ __device__ __forceinline__ void inv_stages2_pre(typename F::E (&x0)[32], typenam
         }
     }
 }
+template <class F, int KHI, int KLO>
+__device__ __forceinline__ void fwd_stages_pre(typename F::E (&x)[32], const typename F::TW (&w)[31], const Limb<F> &P) {
+#pragma unroll
+    for (int k = KHI; k >= KLO; k--) {
+#pragma unroll
+        for (int r = 0; r < 32; r++) {
+            if (r & (1 << k)) continue;
+            F::fwd_bfly(x[r], x[r | (1 << k)], w[(16 >> k) - 1 + (r >> (k + 1))], P);
+        }
+    }
+}
+template <class F, int KLO, int KHI>
+__device__ __forceinline__ void inv_stages_pre(typename F::E (&x)[32], const typename F::TW (&w)[31], const Limb<F> &P) {
+#pragma unroll
+    for (int k = KLO; k <= KHI; k++) {
+#pragma unroll
+        for (int r = 0; r < 32; r++) {
+            if (r & (1 << k)) continue;
+            F::inv_bfly(x[r], x[r | (1 << k)], w[(16 >> k) - 1 + (r >> (k + 1))], P);
+        }
+    }
+}
+// fwd_core / inv_core with the twiddles of each register group issued one exchange ahead (see preload_twiddles): for kernels of the 4-byte
+// field that have ~31 VGPRs to spare (the tensor product: two waves per SIMD either way)
+template <class F, int LOGN>
+__device__ __forceinline__ void fwd_core_pre(typename F::E (&x)[32], typename F::E *lds, uint32_t tid, const Limb<F> &P) {
+    using C = NttCfg<LOGN>;
+    typename F::TW w[31];
+    preload_twiddles<F, LOGN, PatM<LOGN>, 4, 0>(w, tid, P.tw);
+    fwd_stages<F, LOGN, PatA<LOGN>, 4, 0>(x, tid, P.tw, P);
+    lds_put<PatA<LOGN>>(lds, tid, x);
+    __syncthreads();
+    lds_get<PatM<LOGN>>(lds, tid, x);
+    fwd_stages_pre<F, 4, 0>(x, w, P);
+    preload_twiddles<F, LOGN, PatZ<LOGN>, C::REM - 1, 0>(w, tid, P.tw);
+    lds_put<PatM<LOGN>>(lds, tid, x);
+    __syncthreads();
+    lds_get<PatZ<LOGN>>(lds, tid, x);
+    fwd_stages_pre<F, C::REM - 1, 0>(x, w, P);
+}
+template <class F, int LOGN>
+__device__ __forceinline__ void inv_core_pre(typename F::E (&x)[32], typename F::E *lds, uint32_t tid, const Limb<F> &P,
+                                             typename F::E ninv, typename F::E ninv_s, typename F::E ninvw, typename F::E ninvw_s) {
+    using C = NttCfg<LOGN>;
+    typename F::TW w[31];
+    preload_twiddles<F, LOGN, PatZ<LOGN>, 4, 0>(w, tid, P.itw);
+    inv_stages_pre<F, 0, 4>(x, w, P);
+    F::regroup(x, P.q, P.qinv);
+    preload_twiddles<F, LOGN, PatY<LOGN>, 4, 0>(w, tid, P.itw);
+    lds_put<PatZ<LOGN>>(lds, tid, x);
+    __syncthreads();
+    lds_get<PatY<LOGN>>(lds, tid, x);
+    inv_stages_pre<F, 0, 4>(x, w, P);
+    F::regroup(x, P.q, P.qinv);
+    lds_put<PatY<LOGN>>(lds, tid, x);
+    __syncthreads();
+    lds_get<PatA<LOGN>>(lds, tid, x);
+    inv_stages<F, LOGN, PatA<LOGN>, 5 - C::REM, 3>(x, tid, P.itw, P);
+    inv_last_stage<F>(x, P.q, P.q2, ninv, ninv_s, ninvw, ninvw_s);
+}
 // PRESYNC as in fwd_core: the barrier that ends the previous transforms' use of the exchange buffers sits after the first group.
 template <class F, int LOGN, bool PRESYNC = false>
 __device__ __forceinline__ void fwd_core2(typename F::E (&x0)[32], typename F::E (&x1)[32], typename F::E *lds, uint32_t tid,
@@ -437,29 +504,29 @@ __device__ __forceinline__ void fwd_core2(typename F::E (&x0)[32], typename F::E
 }
 
 // NTT values in pattern Z, in [0, 2q)  ->  coefficients in pattern A, in [0, 2q), scaled by the (ninv..) constants
-template <class F, int LOGN, bool TWL = false, bool PRESYNC = false, bool SUB = false>
+template <class F, int LOGN, bool TWL = false, bool PRESYNC = false, bool SUB = false, bool GTW = true>
 __device__ __forceinline__ void inv_core(typename F::E (&x)[32], typename F::E *lds, uint32_t tid, const Limb<F> &P,
                                          typename F::E ninv, typename F::E ninv_s, typename F::E ninvw, typename F::E ninvw_s,
                                          const typename F::TW *twl = nullptr, uint32_t pre = 1) {
     using C = NttCfg<LOGN>;
     const typename F::TW *t2 = TWL ? twl : P.itw;
-    inv_stages<F, LOGN, PatZ<LOGN>, 0, 4, TWL, SUB>(x, tid, t2, P, pre);
+    inv_stages<F, LOGN, PatZ<LOGN>, 0, 4, TWL, SUB, GTW>(x, tid, t2, P, pre);
     F::regroup(x, P.q, P.qinv);
     if constexpr (PRESYNC) __syncthreads();
     lds_put<PatZ<LOGN>>(lds, tid, x);
     __syncthreads();
     lds_get<PatY<LOGN>>(lds, tid, x);
-    inv_stages<F, LOGN, PatY<LOGN>, 0, 4, TWL, SUB>(x, tid, t2, P, pre);
+    inv_stages<F, LOGN, PatY<LOGN>, 0, 4, TWL, SUB, GTW>(x, tid, t2, P, pre);
     F::regroup(x, P.q, P.qinv);
     lds_put<PatY<LOGN>>(lds, tid, x);
     __syncthreads();
     lds_get<PatA<LOGN>>(lds, tid, x);
     if constexpr (SUB) {   // a block of a larger transform: bit LOGN-1 is an ordinary stage, the scaling belongs to the last pass
-        inv_stages<F, LOGN, PatA<LOGN>, 5 - C::REM, 4, false, true>(x, tid, P.itw, P, pre);
+        inv_stages<F, LOGN, PatA<LOGN>, 5 - C::REM, 4, false, true, GTW>(x, tid, P.itw, P, pre);
         F::regroup(x, P.q, P.qinv);
     } else {
         // index bits [10, LOGN-1) <-> r-bits [5-REM, 4) ; bit LOGN-1 <-> r-bit 4 is the scaled last stage
-        inv_stages<F, LOGN, PatA<LOGN>, 5 - C::REM, 3>(x, tid, P.itw, P);
+        inv_stages<F, LOGN, PatA<LOGN>, 5 - C::REM, 3, false, false, GTW>(x, tid, P.itw, P);
         inv_last_stage<F>(x, P.q, P.q2, ninv, ninv_s, ninvw, ninvw_s);
     }
 }
@@ -570,6 +637,10 @@ ntt_multiply_kernel(char *res, const char *a, const char *b,      // no __restri
                     const Limb<F> *__restrict__ limbs, uint32_t L, uint32_t bcast) {
     using C = NttCfg<LOGN>;
     using E = typename F::E;
+    // Under the 128-VGPR cap of four workgroups per CU (4-byte residues) the global_load form of the twiddle loads lets the scheduler
+    // hoist more of them and the kernel spills 5 VGPRs (interleaved A/B at batch 4096: 1.934 M vs 1.946 M polymul/s); this one kernel
+    // keeps the generic-pointer loads and stays scratch-free.  Every other kernel gains from global loads (ct +3..7 %, key switch +8..45 %).
+    constexpr bool GTW = !(sizeof(E) == 4 && MINW >= 4 && !SQUARE);
     __shared__ E lds[C::LDS_ELEMS];
     const uint32_t tid = threadIdx.x, p = blockIdx.x;
     const uint32_t limb = p % L;
@@ -578,21 +649,21 @@ ntt_multiply_kernel(char *res, const char *a, const char *b,      // no __restri
     E x[32];
     load_A<F, LOGN>(a + off, tid, x);
     if constexpr (SQUARE) {
-        fwd_core<F, LOGN>(x, lds, tid, P);
+        fwd_core<F, LOGN, false, false, false, GTW>(x, lds, tid, P);
 #pragma unroll
         for (int r = 0; r < 32; r++) { const E c = F::canon_fwd(x[r], P.q, P.q2, P.qinv); x[r] = F::pw_mul(c, c, P.q, P.qinv); }
     } else {
         E y[32];
         load_A<F, LOGN>(b + (size_t)(bcast ? limb : p) * (C::N * 32), tid, y);   // issued before a's butterflies: b's HBM latency hides under them
-        fwd_core<F, LOGN>(x, lds, tid, P);
+        fwd_core<F, LOGN, false, false, false, GTW>(x, lds, tid, P);
 #pragma unroll
         for (int r = 0; r < 32; r++) x[r] = F::canon_fwd(x[r], P.q, P.q2, P.qinv);   // canonical: keeps x*y < q*2^W
         __syncthreads();                   // all Z-pattern reads of a are done before b overwrites the slots
-        fwd_core<F, LOGN>(y, lds, tid, P);
+        fwd_core<F, LOGN, false, false, false, GTW>(y, lds, tid, P);
 #pragma unroll
         for (int r = 0; r < 32; r++) x[r] = F::pw_mul(x[r], y[r], P.q, P.qinv);   // [0,2q), carries 2^-W
     }
-    inv_core<F, LOGN>(x, lds, tid, P, P.ninv_r, P.ninv_r_s, P.ninvw_r, P.ninvw_r_s);
+    inv_core<F, LOGN, false, false, false, GTW>(x, lds, tid, P, P.ninv_r, P.ninv_r_s, P.ninvw_r, P.ninvw_r_s);
 #pragma unroll
     for (int r = 0; r < 32; r++) x[r] = F::canon_inv(x[r], P.q);
     if constexpr (COMPACT_OUT) {
@@ -866,6 +937,19 @@ ntt_ct_a_kernel(char *__restrict__ c0, char *__restrict__ c1, char *__restrict__
 // two forward transforms instead of four, c1 = 2 a0 a1; 5*S of traffic instead of 7*S.
 // COMPACT_C2: all three outputs go to compact workspace polynomials (see load_A_compact) instead of container buffers: the fused
 // multiply + relinearise, whose key-switch kernel reads them back as digit source (c2) and addends (c0, c1).
+// transforms of the one-launch tensor product: the 4-byte field has the registers to issue each group's twiddles one exchange ahead
+// in the compact-output form (fwd_core_pre / inv_core_pre: 231 VGPRs, two waves per SIMD as before); with container outputs the extra 31
+// registers cost a wave per SIMD (256 VGPRs), and the 8-byte fields have none to spare: those keep the plain form
+template <class F, int LOGN, bool PRE>
+__device__ __forceinline__ void ct_fwd(typename F::E (&x)[32], typename F::E *lds, uint32_t tid, const Limb<F> &P) {
+    if constexpr (PRE) fwd_core_pre<F, LOGN>(x, lds, tid, P); else fwd_core<F, LOGN>(x, lds, tid, P);
+}
+template <class F, int LOGN, bool PRE>
+__device__ __forceinline__ void ct_inv(typename F::E (&x)[32], typename F::E *lds, uint32_t tid, const Limb<F> &P,
+                                       typename F::E ninv, typename F::E ninv_s, typename F::E ninvw, typename F::E ninvw_s) {
+    if constexpr (PRE) inv_core_pre<F, LOGN>(x, lds, tid, P, ninv, ninv_s, ninvw, ninvw_s);
+    else inv_core<F, LOGN>(x, lds, tid, P, ninv, ninv_s, ninvw, ninvw_s);
+}
 template <class F, int LOGN, bool SQUARE = false, bool COMPACT_C2 = false>
 __global__ void __launch_bounds__(NttCfg<LOGN>::T, (sizeof(typename F::E) == 8 && NttCfg<LOGN>::T <= 256) ? 2 : 1)   // 8-byte residues: two workgroups per CU
 ntt_ct_multiply_kernel(char *__restrict__ c0, char *__restrict__ c1, char *__restrict__ c2,
@@ -878,13 +962,14 @@ ntt_ct_multiply_kernel(char *__restrict__ c0, char *__restrict__ c1, char *__res
     const uint32_t tid = threadIdx.x, p = blockIdx.x;
     const Limb<F> P = limbs[p % L];
     const size_t off = (size_t)p * (C::N * 32);
+    constexpr bool CT_PRE = sizeof(E) == 4 && COMPACT_C2 && LOGN <= 14;
     E A0[32], A1[32], B0[32];
     load_A<F, LOGN>(a0 + off, tid, A0);
     load_A<F, LOGN>(a1 + off, tid, A1);
-    fwd_core<F, LOGN>(A0, lds, tid, P);
+    ct_fwd<F, LOGN, CT_PRE>(A0, lds, tid, P);
     if constexpr (SQUARE) {
         __syncthreads();
-        fwd_core<F, LOGN>(A1, lds, tid, P);
+        ct_fwd<F, LOGN, CT_PRE>(A1, lds, tid, P);
 #pragma unroll
         for (int r = 0; r < 32; r++) {
             const E u0 = F::canon_fwd(A0[r], P.q, P.q2, P.qinv), u1 = F::canon_fwd(A1[r], P.q, P.q2, P.qinv);
@@ -896,12 +981,12 @@ ntt_ct_multiply_kernel(char *__restrict__ c0, char *__restrict__ c1, char *__res
         E B1[32];
         load_A<F, LOGN>(b0 + off, tid, B0);
         __syncthreads();
-        fwd_core<F, LOGN>(A1, lds, tid, P);
+        ct_fwd<F, LOGN, CT_PRE>(A1, lds, tid, P);
         load_A<F, LOGN>(b1 + off, tid, B1);
         __syncthreads();
-        fwd_core<F, LOGN>(B0, lds, tid, P);
+        ct_fwd<F, LOGN, CT_PRE>(B0, lds, tid, P);
         __syncthreads();
-        fwd_core<F, LOGN>(B1, lds, tid, P);
+        ct_fwd<F, LOGN, CT_PRE>(B1, lds, tid, P);
 #pragma unroll
         for (int r = 0; r < 32; r++) {
             E u0 = F::canon_fwd(A0[r], P.q, P.q2, P.qinv), u1 = F::canon_fwd(A1[r], P.q, P.q2, P.qinv);   // canonical a-side
@@ -911,7 +996,7 @@ ntt_ct_multiply_kernel(char *__restrict__ c0, char *__restrict__ c1, char *__res
             B0[r] = F::pw_mul(u1, v1, P.q, P.qinv);
         }
     }
-    inv_core<F, LOGN>(A0, lds, tid, P, P.ninv_r, P.ninv_r_s, P.ninvw_r, P.ninvw_r_s);
+    ct_inv<F, LOGN, CT_PRE>(A0, lds, tid, P, P.ninv_r, P.ninv_r_s, P.ninvw_r, P.ninvw_r_s);
 #pragma unroll
     for (int r = 0; r < 32; r++) A0[r] = F::canon_inv(A0[r], P.q);
     if constexpr (COMPACT_C2) {
@@ -922,7 +1007,7 @@ ntt_ct_multiply_kernel(char *__restrict__ c0, char *__restrict__ c1, char *__res
         store_from_lds<F, LOGN>(c0 + off, lds, tid);
     }
     __syncthreads();
-    inv_core<F, LOGN>(A1, lds, tid, P, P.ninv_r, P.ninv_r_s, P.ninvw_r, P.ninvw_r_s);
+    ct_inv<F, LOGN, CT_PRE>(A1, lds, tid, P, P.ninv_r, P.ninv_r_s, P.ninvw_r, P.ninvw_r_s);
 #pragma unroll
     for (int r = 0; r < 32; r++) A1[r] = F::canon_inv(A1[r], P.q);
     if constexpr (COMPACT_C2) {
@@ -933,7 +1018,7 @@ ntt_ct_multiply_kernel(char *__restrict__ c0, char *__restrict__ c1, char *__res
         store_from_lds<F, LOGN>(c1 + off, lds, tid);
     }
     __syncthreads();
-    inv_core<F, LOGN>(B0, lds, tid, P, P.ninv_r, P.ninv_r_s, P.ninvw_r, P.ninvw_r_s);
+    ct_inv<F, LOGN, CT_PRE>(B0, lds, tid, P, P.ninv_r, P.ninv_r_s, P.ninvw_r, P.ninvw_r_s);
 #pragma unroll
     for (int r = 0; r < 32; r++) B0[r] = F::canon_inv(B0[r], P.q);
     if constexpr (COMPACT_C2) {

@@ -4,7 +4,7 @@
 cd "$(dirname "$0")/../gpu-homomorphic-encryption_amd/csrc" || exit 1
 OUT=$(mktemp -d)
 for i in "$@"; do set -- $i
-  (/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 --cuda-device-only -DFHE_FIELD=$1 -DFHE_LOGN=$2 \
+  (/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 --cuda-device-only -mllvm -pragma-unroll-threshold=1000000 -DFHE_FIELD=$1 -DFHE_LOGN=$2 \
      -Rpass-analysis=kernel-resource-usage -c -o $OUT/x_$1_$2.o lds_inst.hip 2>&1 |
    grep -E "Function Name|    VGPRs:|VGPRs Spill|Occupancy" | paste - - - - |
    sed 's/\[-Rpass[^]]*\]//g; s/[^ ]*ntt_lds.hip.h:[0-9:]* //g; s/remark: //g; s/Function Name: _ZN7fhe_dev[0-9]*//; s/INS_\(F[0-9]*\)ELi\([0-9]*\)\([A-Za-z0-9]*\)EEv[^ \t]*/ \1 \2 \3/' |

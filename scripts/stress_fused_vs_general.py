@@ -23,6 +23,8 @@ while time.time() - t0 < budget:
     L = int(rng.integers(1, 7 if bits == 30 else 4))
     w = int(rng.choice([8, 16, 20, 30])) if bits == 30 else int(rng.choice([16, 20, 32]))
     batch = int(rng.integers(1, 41)) if log_n <= 13 else int(rng.integers(1, 9))
+    if cases % 16 == 15:          # a batch large enough for the two-stream pipeline of fhe_ct_multiply_relin (>= 1024 limb polynomials per chunk)
+        log_n, n, bits, L, w, batch = 12, 4096, 30, 4, int(rng.choice([16, 30])), int(rng.integers(512, 600))
     moduli = pkg.find_ntt_primes(bits, n, L)
     # the environment switches are read once, at engine creation: one engine per kernel family
     def make(**env):
@@ -35,7 +37,10 @@ while time.time() - t0 < budget:
                 os.environ.pop(k, None)
     engs = {"fused": make(), "general": make(FHE_HIP_NO_FUSED_KEYSWITCH="1", FHE_HIP_NO_FUSED_BLIND_ROTATE="1"),
             "fused-single": make(FHE_HIP_NO_PAIRED_TRANSFORMS="1"),
-            "fused-alt": make(FHE_HIP_NO_TWO_LAUNCH_CT="1", FHE_HIP_SPLIT_KEYSWITCH="1")}   # the other forms of the N = 2^14 / 2^15 kernels
+            "fused-alt": make(FHE_HIP_NO_TWO_LAUNCH_CT="1", FHE_HIP_SPLIT_KEYSWITCH="1"),   # the other forms of the N = 2^14 / 2^15 kernels
+            # the round-2 forms of what round 3 changed: c2 / accumulators as containers, monomial factor per digit, one stream
+            "fused-r2": make(FHE_HIP_NO_C2_COMPACTION="1", FHE_HIP_NO_PREROTATION="1", FHE_HIP_CT_RELIN_CHUNKS="1",
+                             **({"FHE_HIP_NO_COMPACT_BLIND_ROTATE": "1"} if cases % 2 else {}))}
     K = engs["fused"].relin_num_digits(w)
     seed = int(rng.integers(1 << 30))
     keys = [[pkg.DeviceBuffer.from_numpy(rns_poly(seed + 31 * i + 997 * h, moduli, n, 1)) for i in range(L * K)] for h in range(4)]
@@ -45,7 +50,7 @@ while time.time() - t0 < budget:
     # relinearisation, repeated: every repetition must give the same bits
     want = None
     for rep in range(4):
-        for tag in ("general", "fused", "fused-single", "fused-alt"):
+        for tag in ("general", "fused", "fused-single", "fused-alt", "fused-r2"):
             d = [pkg.DeviceBuffer.from_numpy(x) for x in c]
             engs[tag].relinearize(keysets[tag][0], d[0], d[1], d[2], batch); launches += 1
             got = (d[0].download(shape), d[1].download(shape))
@@ -57,7 +62,7 @@ while time.time() - t0 < budget:
     ops = [rns_poly(seed + 7000 + i, moduli, n, batch) for i in range(4)]
     want = None
     for rep in range(2):
-        for tag in ("general", "fused", "fused-single", "fused-alt"):
+        for tag in ("general", "fused", "fused-single", "fused-alt", "fused-r2"):
             d = [pkg.DeviceBuffer.from_numpy(x) for x in ops]
             o = [pkg.DeviceBuffer(ops[0].nbytes) for _ in range(3)]
             if tag == "general":
@@ -76,7 +81,7 @@ while time.time() - t0 < budget:
     dSh = pkg.DeviceBuffer.from_numpy(shifts)
     want = None
     for rep in range(3):
-        for tag in ("general", "fused", "fused-single", "fused-alt"):
+        for tag in ("general", "fused", "fused-single", "fused-alt", "fused-r2"):
             a0, a1 = pkg.DeviceBuffer.from_numpy(c[0]), pkg.DeviceBuffer.from_numpy(c[1])
             t0b, t1b = pkg.DeviceBuffer(c[0].nbytes), pkg.DeviceBuffer(c[0].nbytes)
             engs[tag].blind_rotate([keysets[tag][0]] * steps, [keysets[tag][1]] * steps, a0, a1, dSh, t0b, t1b, batch); launches += steps

@@ -24,9 +24,10 @@ def fail(what, **kw):
 
 
 while time.time() - t0 < budget:
-    log_n = int(rng.integers(11, 16)); n = 1 << log_n
-    bits = int(rng.choice([30, 30, 40, 60, 64])) if log_n <= 14 else 30
-    L = int(rng.integers(1, 5))
+    log_n = int(rng.integers(11, 17)); n = 1 << log_n
+    # N = 2^16 on 4-byte residues and N = 2^15 / 2^16 on 8-byte residues are the two-pass sizes (compact workspace between the launches)
+    bits = int(rng.choice([30, 30, 40, 60, 64])) if log_n <= 15 else int(rng.choice([30, 30, 40, 64]))
+    L = int(rng.integers(1, 5)) if log_n <= 14 else int(rng.integers(1, 3))
     batch = int(rng.integers(1, 13)) if log_n <= 13 else int(rng.integers(1, 4))
     moduli = pkg.find_ntt_primes(bits, n, L)
     os.environ.pop("FHE_HIP_FORCE_WIDTH", None)

@@ -38,11 +38,25 @@ if trace:
                                           "scratch": r.get("Scratch_Size"), "wg": r.get("Workgroup_Size"), "grid": r.get("Grid_Size")})
     for k, v in res.items():
         summary["kernels"].setdefault(k, {}).update(v)
-for kind, key in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+def steps_of(log):
+    """steps + warmup of the bench.py run a PMC pass profiled (its JSON line), so that counters can be given per STEP."""
+    p = os.path.join(src, log)
+    if os.path.exists(p):
+        for line in open(p):
+            if line.startswith("{") and '"metric"' in line:
+                d = json.loads(line)
+                return d["steps"] + d["warmup"]
+    return None
+
+
+# FETCH_SIZE x 2, WRITE_SIZE x 1 for every kernel: measured per access shape in profiles/r03_fetch_calibration.txt (2.000 / 1.000 for all
+# sixteen load / store shapes the kernels use, scripts/fetch_calibration.sh)
+for kind, key, log in (("fetch", "FETCH_SIZE", "bench_pmc_fetch.log"), ("write", "WRITE_SIZE", "bench_pmc_write.log")):
     f = one(f"pmc_{kind}/*/*_counter_collection.csv")
     if not f:
         continue
     shutil.copy(f, f"profiles/{tag}_pmc_{kind}.csv")
+    nsteps = steps_of(log)
     acc = {}
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] == key:
@@ -51,13 +65,15 @@ for kind, key in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
         kib = sum(vals) / len(vals)
         d = summary["kernels"].setdefault(k, {})
         d[key + "_KiB_per_launch_raw"] = kib
-        if key == "FETCH_SIZE":
-            d["hbm_read_bytes_per_launch"] = kib * 1024 * 2      # gfx950: counter reports 1/2 of streamed bytes
-        else:
-            d["hbm_write_bytes_per_launch"] = kib * 1024
+        mul = 2 if key == "FETCH_SIZE" else 1
+        d["hbm_read_bytes_per_launch" if key == "FETCH_SIZE" else "hbm_write_bytes_per_launch"] = kib * 1024 * mul
+        if nsteps:      # per STEP of the workload (a step may launch a kernel several times, or several kernels): total over the run / steps of the run
+            d["hbm_read_bytes_per_step" if key == "FETCH_SIZE" else "hbm_write_bytes_per_step"] = sum(vals) * 1024 * mul / nsteps
 for k, d in summary["kernels"].items():
     if "hbm_read_bytes_per_launch" in d and "hbm_write_bytes_per_launch" in d:
         d["hbm_bytes_per_launch"] = d["hbm_read_bytes_per_launch"] + d["hbm_write_bytes_per_launch"]
+    if "hbm_read_bytes_per_step" in d and "hbm_write_bytes_per_step" in d:
+        d["hbm_bytes_per_step"] = d["hbm_read_bytes_per_step"] + d["hbm_write_bytes_per_step"]
 for log in ("bench_trace.log",):
     p = os.path.join(src, log)
     if os.path.exists(p):
