@@ -246,6 +246,7 @@ struct fhe_rns_ntt {
     hipStream_t own_stream = nullptr, stream = nullptr;
     hipStream_t aux_stream = nullptr;   // second stream of the overlapped one-call multiply (fork / join with events around it)
     hipEvent_t ev_chunk[16] = {}, ev_join = nullptr;   // tensor product of chunk i done (engine stream) -> key switch of chunk i may start (second stream)
+    uint32_t small_batch_polys = 256;   // FHE_HIP_SMALL_BATCH_POLYS: fused multiply of at most this many limb polynomials runs the 16-per-thread latency kernel (0 = never)
     uint32_t overlap_chunks = 4;        // FHE_HIP_CT_RELIN_CHUNKS: pieces the one-call multiply is cut into (1 = one stream, as in round 2)
     void *d_limbs = nullptr;            // owned by d_tables
     void *d_wlimbs = nullptr;           // FHE_WIDTH_256: WLimb<wide_nl>[L] for the NTT kernels of ntt_wide.hip.h (owned by d_tables)
@@ -540,6 +541,7 @@ static int create_impl(fhe_rns_ntt **out, uint32_t n, const uint64_t (*moduli)[4
     h->no_compact_blind_rotate = getenv("FHE_HIP_NO_COMPACT_BLIND_ROTATE") != nullptr;
     h->no_two_launch_ct = getenv("FHE_HIP_NO_TWO_LAUNCH_CT") != nullptr;
     h->split_keyswitch = getenv("FHE_HIP_SPLIT_KEYSWITCH") != nullptr;
+    if (const char *m = getenv("FHE_HIP_SMALL_BATCH_POLYS")) { const long v = atol(m); h->small_batch_polys = v < 0 ? 0u : (uint32_t)v; }
     if (const char *m = getenv("FHE_HIP_CT_RELIN_CHUNKS")) { const int v = atoi(m); h->overlap_chunks = v < 1 ? 1 : v > 16 ? 16 : (uint32_t)v; }
     h->no_prerotation = getenv("FHE_HIP_NO_PREROTATION") != nullptr;       // blind-rotation loop of the three-array kernels: monomial factor inside the kernel, per digit (A/B, cross-check)
     h->no_c2_compaction = getenv("FHE_HIP_NO_C2_COMPACTION") != nullptr;   // stand-alone relinearisation of the 8-byte fields: c2 read as containers (A/B, cross-check)
@@ -743,6 +745,7 @@ static int lds_run(fhe_rns_ntt *h, int op, void *r0, void *r1, void *r2, const v
     fhe_dev::LdsArgs A{op, r0, r1, r2, a0, a1, b0, b1, h->d_limbs, h->L, polys, h->stream};
     A.single_transforms = h->single_transforms;
     A.b_polys = b_polys;
+    A.small_batch = op == fhe_dev::LDS_MULTIPLY && polys <= h->small_batch_polys;
     A.square = !b_polys && !h->no_square &&
                ((op == fhe_dev::LDS_MULTIPLY && a0 == b0) || (op == fhe_dev::LDS_CT_MULTIPLY && a0 == b0 && a1 == b1));
     if (op == fhe_dev::LDS_CT_MULTIPLY) { int rc = ct_workspace(h, A); if (rc) return rc; }

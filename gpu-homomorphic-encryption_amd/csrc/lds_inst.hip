@@ -2,11 +2,24 @@
 // Compile with -DFHE_FIELD=F32|F52|F64|F64X -DFHE_LOGN=11..15 (the Makefile lists the instances).
 #include "lds_launch.h"
 #include "ntt_lds.hip.h"
+#include "ntt_lds_small.hip.h"
 
 #define CAT_(a, b, c) a##b##_##c
 #define CAT(a, b, c) CAT_(a, b, c)
 
 namespace fhe_dev {
+
+// the latency kernel where it exists (a template so that the other instances do not instantiate Cfg16 at all); b == a simply loads twice
+template <class F, int LOGN>
+static bool launch_small_multiply(const LdsArgs &A, const Limb<F> *limbs) {
+    if constexpr (lds_small_multiply(sizeof(typename F::E), LOGN)) {
+        hipLaunchKernelGGL((ntt16_multiply_kernel<F, LOGN>), dim3(A.polys), dim3(Cfg16<LOGN>::T), 0, A.stream, (char *)A.r0, (const char *)A.a0,
+                           (const char *)A.b0, limbs, A.L, A.b_polys ? 1u : 0u);
+        return true;
+    } else {
+        return false;
+    }
+}
 
 void CAT(lds_launch_, FHE_FIELD, FHE_LOGN)(const LdsArgs &A) {
     using F = FHE_FIELD;
@@ -49,6 +62,7 @@ void CAT(lds_launch_, FHE_FIELD, FHE_LOGN)(const LdsArgs &A) {
             hipLaunchKernelGGL((ntt_inverse_kernel<F, LOGN>), grid, block, 0, A.stream, (char *)A.r0, limbs, A.L);
             break;
         case LDS_MULTIPLY:
+            if (A.small_batch && launch_small_multiply<F, LOGN>(A, limbs)) break;   // few polynomials: one workgroup's latency is what counts (ntt_lds_small.hip.h)
             if (A.square)
                 hipLaunchKernelGGL((ntt_multiply_kernel<F, LOGN, MULT_MINW, true>), grid, block, 0, A.stream, (char *)A.r0, (const char *)A.a0,
                                    (const char *)A.b0, limbs, A.L, 0u);
@@ -194,3 +208,8 @@ void CAT(lds_launch_, FHE_FIELD, FHE_LOGN)(const LdsArgs &A) {
 }
 
 }  // namespace fhe_dev
+
+#if defined(FHE_STAMPS) && FHE_LOGN == 13
+// diagnostic build only: the s_memtime stamps of the last ntt16_multiply_kernel launch of this instance
+extern "C" int fhe_debug_stamps16(unsigned long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(fhe_dev::g_stamps16), 16 * sizeof(unsigned long long)); }
+#endif

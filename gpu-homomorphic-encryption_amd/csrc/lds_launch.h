@@ -45,6 +45,10 @@ constexpr bool lds_paired_extprod(int elem_bytes, int log_n) { return elem_bytes
 // key-switch kernel exists in its default one-launch form: paired (4-byte residues up to 2^14) or split (8-byte residues, N = 2^15)
 constexpr bool lds_compact_c2(int elem_bytes, int log_n) { return lds_keyswitch_split(elem_bytes, log_n) || lds_paired_keyswitch(elem_bytes, log_n); }
 
+// LDS_MULTIPLY for few polynomials (LdsArgs::small_batch, set by the host while batch x limbs is below the CU count): the 16-per-thread
+// latency kernel of ntt_lds_small.hip.h; 4-byte residues only (its 90 preloaded 4-byte twiddles fit the register file, 8-byte ones do not)
+constexpr bool lds_small_multiply(int elem_bytes, int log_n) { return elem_bytes == 4 && log_n <= 14; }
+
 struct LdsArgs {
     int op;
     void *r0, *r1, *r2;                  // outputs (forward / inverse: r0 is the in-place buffer)
@@ -70,6 +74,8 @@ struct LdsArgs {
     void *ws = nullptr;                  // LDS_CT_MULTIPLY where !lds_ct_fused: 2 * polys * n residues of workspace for the transformed b-side
     uint32_t top = 0;                    // LDS_PASS_* / LDS_SUB_*: number of stages above the 2^13 blocks (log2 n = 13 + top)
     bool rconst = false;                 // LDS_PASS_INV: scale with the constants that also absorb the 2^-W of a fused pointwise product
+    // (new members go at the END: objects of the other instances stay layout-compatible during development, scripts/dev_relink.sh)
+    bool small_batch = false;            // LDS_MULTIPLY: use the latency kernel where lds_small_multiply holds (never with compact_c2)
 };
 
 typedef void (*lds_launch_fn)(const LdsArgs &);

@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""Small-batch latency of the fused polymul (configs[2]'s batch-1 shape): per-call time at batch 1 .. 256 with the latency kernel
+(default below 128 limb polynomials) and with the throughput kernel forced (FHE_HIP_SMALL_BATCH_POLYS=0), plus the launch floor.
+Writes one JSON line per (batch, kernel) to gpurun_out/small_batch_<tag>.jsonl.   usage: bench_small_batch2.py [tag] [batches, comma separated]"""
+import importlib, json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+pkg = importlib.import_module("gpu-homomorphic-encryption_amd")
+from workload import rns_poly  # noqa: E402
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+n, L = 8192, 4
+moduli = pkg.find_ntt_primes(30, n, L)
+out = open(os.path.join(ROOT, "gpurun_out", f"small_batch_{tag}.jsonl"), "w")
+def engine(polys):
+    if polys is not None: os.environ["FHE_HIP_SMALL_BATCH_POLYS"] = str(polys)
+    try: return pkg.RnsNttEngine(n, moduli)
+    finally: os.environ.pop("FHE_HIP_SMALL_BATCH_POLYS", None)
+engs = {"latency-kernel": engine(1000000), "throughput-kernel": engine(0), "default": engine(None)}
+BATCHES = [int(v) for v in sys.argv[2].split(',')] if len(sys.argv) > 2 else [1, 2, 4, 8, 16, 32, 64, 128, 256]
+for B in BATCHES:
+    a = pkg.DeviceBuffer.from_numpy(rns_poly(1, moduli, n, B)); b = pkg.DeviceBuffer.from_numpy(rns_poly(2, moduli, n, B)); r = pkg.DeviceBuffer(B * L * n * 32)
+    for name, e in engs.items():
+        for _ in range(20): e.multiply(r, a, b, B)
+        pkg.capi.sync(); t = pkg.Timer(); steps = 400
+        t.start(e)
+        for _ in range(steps): e.multiply(r, a, b, B)
+        t.stop(e); pkg.capi.sync()
+        us = t.elapsed_ms() * 1e3 / steps
+        line = {"op": "multiply", "n": n, "limbs": L, "batch": B, "kernel": name, "us_per_call": us, "polymul_per_s": B / (us * 1e-6)}
+        out.write(json.dumps(line) + "\n"); print(line, flush=True)

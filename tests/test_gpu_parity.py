@@ -115,7 +115,7 @@ def _moduli(spec, n):
 
 
 @pytest.mark.parametrize("n,spec,batch,width", CASES)
-def test_forward_inverse_multiply_match_oracle(eng, oracle, n, spec, batch, width):
+def test_forward_inverse_multiply_match_oracle(eng, oracle, monkeypatch, n, spec, batch, width):
     moduli = _moduli(spec, n)
     L = len(moduli)
     e = eng.RnsNttEngine(n, moduli)
@@ -143,8 +143,20 @@ def test_forward_inverse_multiply_match_oracle(eng, oracle, n, spec, batch, widt
     assert np.array_equal(dR.download(shape), want_pw)
     # multiply: operands preserved, result == oracle polymul
     e.multiply(dR, dA, dB, batch)
-    assert np.array_equal(dR.download(shape), rp.polymul(a, b, threads=8))
+    want_mul = rp.polymul(a, b, threads=8)
+    assert np.array_equal(dR.download(shape), want_mul)
     assert np.array_equal(dA.download(shape), a) and np.array_equal(dB.download(shape), b)
+    if width == eng.WIDTH_32 and n <= 16384:
+        # few polynomials run the 16-per-thread latency kernel (ntt_lds_small.hip.h) by default: the throughput kernel on the same operands,
+        # and the latency kernel forced for any batch, must give the same containers
+        for polys in ("0", "1000000"):
+            monkeypatch.setenv("FHE_HIP_SMALL_BATCH_POLYS", polys)
+            e2 = eng.RnsNttEngine(n, moduli)
+            monkeypatch.delenv("FHE_HIP_SMALL_BATCH_POLYS")
+            dR.zero(); e2.multiply(dR, dA, dB, batch)
+            assert np.array_equal(dR.download(shape), want_mul), polys
+            dC = _up(eng, a); e2.multiply(dC, dC, dB, batch)                    # in place on the first operand
+            assert np.array_equal(dC.download(shape), want_mul), polys
     # add / sub
     e.poly_add(dR, dA, dB, batch)
     want = np.stack([np.stack([oracle.batch_add(np.ascontiguousarray(a[bi, l]), np.ascontiguousarray(b[bi, l]), moduli[l])

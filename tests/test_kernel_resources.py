@@ -94,6 +94,17 @@ def test_streaming_kernels_keep_four_workgroups_per_cu(resources):
         assert k.get("scratch", 0) == 0 and k["occupancy"] == 8, k
 
 
+def test_small_batch_latency_kernel(resources):
+    """ntt16_multiply_kernel (few polynomials, ntt_lds_small.hip.h): 512 threads at N = 8192 with every twiddle of its three transforms in registers --
+    it must not spill (the point is latency) and its exchange image is the unpadded N x 4 bytes."""
+    kernels, _ = resources[("F32", 13)]
+    for k in _all(kernels, "ntt16_multiply_kernel", 1):
+        assert k["spill"] == 0 and k.get("scratch", 0) == 0 and k["vgprs"] <= 256 and k["occupancy"] >= 2 and k["lds"] == 32768, k
+    kernels14, _ = resources[("F32", 14)]
+    for k in _all(kernels14, "ntt16_multiply_kernel", 1):        # 1024 threads: 128 VGPRs per lane
+        assert k["vgprs"] <= 128 and k.get("scratch", 0) <= 256 and k["lds"] == 65536, k
+
+
 def test_compute_bound_kernels_do_not_spill(resources):
     kernels, _ = resources[("F32", 13)]
     for name, variants, lds in (("ntt_ct_multiply_kernel", 3, 33792), ("ntt_keyswitch2_kernel", 2, 2 * 33792), ("ntt_extprod2_kernel", 4, 2 * 33792)):
@@ -110,9 +121,11 @@ def test_f32_n16384_instance(resources):
     for name in ("ntt_forward_kernel", "ntt_inverse_kernel", "ntt_multiply_kernel"):
         for k in _all(kernels, name):
             assert k["vgprs"] <= 128 and k["occupancy"] >= 4 and k.get("scratch", 0) <= 12 and k["lds"] == 67584, (name, k)
-    for name, lds in (("ntt_ct_multiply_kernel", 67584), ("ntt_keyswitch2_kernel", 135168), ("ntt_extprod2_kernel", 135168)):
+    # the paired external product issues its twiddles one exchange ahead (31 more live registers, round 3: +13 % at this size) and parks
+    # 6-12 VGPRs (28-52 B per lane) at the 256-VGPR cap; the key switch and the tensor product stay scratch-free
+    for name, lds, cap in (("ntt_ct_multiply_kernel", 67584, 0), ("ntt_keyswitch2_kernel", 135168, 0), ("ntt_extprod2_kernel", 135168, 64)):
         for k in _all(kernels, name):
-            assert k.get("scratch", 0) == 0 and k["vgprs"] <= 256 and k["occupancy"] >= 2 and k["lds"] == lds, (name, k)
+            assert k.get("scratch", 0) <= cap and k["vgprs"] <= 256 and k["occupancy"] >= 2 and k["lds"] == lds, (name, k)
 
 
 def test_f52_n16384_instance(resources):
@@ -128,13 +141,18 @@ def test_f52_n16384_instance(resources):
     # form parks part of the canonical a-side across the inverse transform + store (132 B today, 644 B with flat addresses)
     for k in _all(kernels, "ntt_ct_a_kernelINS_3F52ELi14ELi2ELb1E"):
         assert k.get("scratch", 0) == 0, k
-    # bytes per lane today: mac2 160 / split key switch 216 / split external product 360; three-array key switch 152-160 (444 with flat
-    # addresses: the compiler hoisted 34 64-bit address pairs out of the digit loops and spilled them), external product 624
-    bounds = {"ntt_mac2_kernel": 200, "ntt_keyswitch_kernel": 260, "ntt_extprod_kernel": 420, "ntt_ct_a_kernel": 200, "ntt_keyswitch3_kernel": 220,
-              "ntt_extprod3_kernel": 720}
+    # bytes per lane today (round 3, twiddle loads as global_load): mac2 140-224 / split key switch 216 / split external product 360; three-array key
+    # switch 68-116 (152-160 in round 2, 444 with flat addresses); three-array external product with the pre-rotated digit source (the form
+    # fhe_blind_rotate runs) 176, with the rotation inside the kernel (FHE_HIP_NO_PREROTATION=1, a cross-check) 870-920 -- that code is what spilled
+    bounds = {"ntt_mac2_kernel": 260, "ntt_keyswitch_kernel": 260, "ntt_extprod_kernel": 420, "ntt_ct_a_kernel": 200, "ntt_keyswitch3_kernel": 140}
     for name, cap in bounds.items():
         for k in _all(kernels, name):
             assert k["vgprs"] <= 256 and k["occupancy"] >= 2 and k.get("scratch", 0) <= cap, (name, k)
+    for mangled, k in kernels.items():
+        if "ntt_extprod3_kernel" in mangled:
+            prerot = re.search(r"ntt_extprod3_kernelINS_3F52ELi14ELi2ELb[01]ELb[01]ELb1E", mangled) is not None
+            assert k["vgprs"] <= 256 and k["occupancy"] >= 2 and k.get("scratch", 0) <= (200 if prerot else 1000), (mangled, k)
+    assert any(re.search(r"ntt_extprod3_kernelINS_3F52ELi14ELi2ELb1ELb[01]ELb1E", m) for m in kernels)
 
 
 def test_full_width_tile_kernels(resources):
