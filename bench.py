@@ -281,6 +281,32 @@ def extra_width_classes(pkg, steps=10, warmup=2):
     return out
 
 
+def extra_workloads():
+    """The other BASELINE configurations on their single-GPU shapes, each a short child run of this script (outside the headline timing), so that the
+    driver's record carries them beside the configs[1] line: configs[2] = full ciphertext multiply N = 8192, log_q = 120 (fhe_ct_multiply_relin) and its
+    relinearisation alone; configs[3] = the same at N = 16384, 6 limbs, 128 ciphertexts (= 1024 / 8 GPUs); configs[4] = the blind-rotation loop at that shape."""
+    import subprocess
+    specs = [("configs[2] ctrelin N=8192 4x30-bit w=16", ["--op", "ctrelin", "--batch", "1024"]),
+             ("configs[2] relin alone", ["--op", "relin", "--batch", "1024"]),
+             ("configs[3] ctrelin N=16384 6x30-bit, 128 ciphertexts per GPU", ["--op", "ctrelin", "--batch", "128", "--n", "16384", "--limbs", "6"]),
+             ("configs[3] on 40-bit primes", ["--op", "ctrelin", "--batch", "128", "--n", "16384", "--limbs", "6", "--bits", "40"]),
+             ("configs[4] blind-rotation loop N=16384 6x30-bit w=16, 8 steps", ["--op", "blindrotate", "--batch", "128", "--n", "16384", "--limbs", "6"]),
+             ("configs[4] on 40-bit primes", ["--op", "blindrotate", "--batch", "128", "--n", "16384", "--limbs", "6", "--bits", "40", "--steps", "3"])]
+    out = []
+    for name, extra in specs:
+        try:
+            args = [sys.executable, os.path.abspath(__file__), "--no-extras", "--no-cpu-baseline", "--steps", "5", "--warmup", "1"] + extra
+            res = subprocess.run(args, capture_output=True, text=True, timeout=300)
+            d = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][0])
+            r = d["roofline"]
+            out.append({"workload": name, "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "batch": d["config"]["batch_per_gpu"],
+                        "dtype": d["dtype"], "hbm_frac": r["frac"], "algorithmic_bytes_per_launch": r["algorithmic_bytes_per_launch"],
+                        "int_mul_frac": r["secondary"]["frac"], "limiter": r["limiter"], "verified": d.get("verified")})
+        except Exception as e:                       # an extra must never take the headline down
+            out.append({"workload": name, "error": str(e)[:200]})
+    return out
+
+
 def cpu_baseline(n, moduli, target_core_seconds=16.0):
     """CPU oracle (oracle/fhe_oracle.c, OpenMP over batch x limb) on a bounded sample of the same workload."""
     from oracle import pyoracle as orc
@@ -576,6 +602,8 @@ def main():
     out["dist_backend"] = None if dist is None else (args.dist_backend + (" (RCCL over xGMI)" if args.dist_backend == "nccl" else " (CPU rehearsal)"))
     if rank == 0 and world == 1 and not args.no_extras and args.op == "multiply":
         out["extra_width_classes"] = extra_width_classes(pkg)
+    if rank == 0 and world == 1 and not args.no_extras and args.op == "multiply" and args.shard == "batch":
+        out["extra_workloads"] = extra_workloads()
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.op == "multiply":
         out["cpu_baseline"] = cpu_baseline(n, moduli)
     if rank == 0:

@@ -247,6 +247,7 @@ struct fhe_rns_ntt {
     hipStream_t aux_stream = nullptr;   // second stream of the overlapped one-call multiply (fork / join with events around it)
     hipEvent_t ev_chunk[16] = {}, ev_join = nullptr;   // tensor product of chunk i done (engine stream) -> key switch of chunk i may start (second stream)
     uint32_t small_batch_polys = 256;   // FHE_HIP_SMALL_BATCH_POLYS: fused multiply of at most this many limb polynomials runs the 16-per-thread latency kernel (0 = never)
+    bool relin_chunks_forced = false;   // FHE_HIP_RELIN_PIPELINE=1: the stand-alone relinearisation also runs as a two-stream pipeline (A/B)
     uint32_t overlap_chunks = 4;        // FHE_HIP_CT_RELIN_CHUNKS: pieces the one-call multiply is cut into (1 = one stream, as in round 2)
     void *d_limbs = nullptr;            // owned by d_tables
     void *d_wlimbs = nullptr;           // FHE_WIDTH_256: WLimb<wide_nl>[L] for the NTT kernels of ntt_wide.hip.h (owned by d_tables)
@@ -542,6 +543,7 @@ static int create_impl(fhe_rns_ntt **out, uint32_t n, const uint64_t (*moduli)[4
     h->no_two_launch_ct = getenv("FHE_HIP_NO_TWO_LAUNCH_CT") != nullptr;
     h->split_keyswitch = getenv("FHE_HIP_SPLIT_KEYSWITCH") != nullptr;
     if (const char *m = getenv("FHE_HIP_SMALL_BATCH_POLYS")) { const long v = atol(m); h->small_batch_polys = v < 0 ? 0u : (uint32_t)v; }
+    h->relin_chunks_forced = getenv("FHE_HIP_RELIN_PIPELINE") != nullptr;
     if (const char *m = getenv("FHE_HIP_CT_RELIN_CHUNKS")) { const int v = atoi(m); h->overlap_chunks = v < 1 ? 1 : v > 16 ? 16 : (uint32_t)v; }
     h->no_prerotation = getenv("FHE_HIP_NO_PREROTATION") != nullptr;       // blind-rotation loop of the three-array kernels: monomial factor inside the kernel, per digit (A/B, cross-check)
     h->no_c2_compaction = getenv("FHE_HIP_NO_C2_COMPACTION") != nullptr;   // stand-alone relinearisation of the 8-byte fields: c2 read as containers (A/B, cross-check)
@@ -579,6 +581,14 @@ static int grow_ws(fhe_rns_ntt *h, void **ws, size_t *have, size_t bytes) {
 // d_ws : general paths (the reference mallocs/frees per multiply, src/ntt.cu:51-74) and the transformed b-side of the two-launch tensor product
 // d_ws2: c0, c1, c2 of the fused multiply + relinearise and the compact accumulators of a blind-rotation loop
 // d_ws3: the compact polynomials between the two launches of a two-pass transform (N beyond the LDS range)
+// second stream + events of the chunked two-stage pipelines (fhe_ct_multiply_relin, stand-alone relinearisation): created on first use
+static int ensure_aux_stream(fhe_rns_ntt *h) {
+    if (h->aux_stream) return FHE_OK;
+    HIP_TRY(hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+    for (hipEvent_t &e : h->ev_chunk) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    return FHE_OK;
+}
 static int ensure_ws(fhe_rns_ntt *h, size_t bytes) { return grow_ws(h, &h->d_ws, &h->ws_bytes, bytes); }
 static int ensure_ws2(fhe_rns_ntt *h, size_t bytes) { return grow_ws(h, &h->d_ws2, &h->ws2_bytes, bytes); }
 static int ensure_ws3(fhe_rns_ntt *h, size_t bytes) { return grow_ws(h, &h->d_ws3, &h->ws3_bytes, bytes); }
@@ -1187,13 +1197,39 @@ extern "C" int fhe_ct_relinearize(fhe_rns_ntt_t *h, const fhe_relin_keys_t *rk, 
         A.single_transforms = h->single_transforms;
         A.joint3 = use_joint3(h, false, false);
         const bool c2_in_ws2 = h->d_ws2 && (const char *)d_c2 >= (const char *)h->d_ws2 && (const char *)d_c2 < (const char *)h->d_ws2 + h->ws2_bytes;
-        if (A.joint3 && h->width != FHE_WIDTH_32 && !h->no_c2_compaction && !c2_in_ws2) {   // (c2 already in the workspace: the composed multiply + relinearise under a testing switch)
-            // the three-array kernel re-reads c2 for every digit from each of the L limb workgroups: compact it once (S read, S/4 written)
-            // so that those L*K reads move S/4 instead of S (round 2 counters at N = 2^14, 6 x 40-bit: 2.6 x the algorithmic bytes)
-            const size_t containers = (size_t)batch * h->L * h->n;
-            if ((rc = ensure_ws2(h, containers * 8))) return rc;
-            if ((rc = compact_poly(h, h->d_ws2, d_c2, containers))) return rc;
-            A.a0 = h->d_ws2; A.c2_only_compact = true;
+        const size_t eb = residue_bytes(h), S = (size_t)h->L * h->n * 32, Sc = (size_t)h->L * h->n * eb;
+        const bool paired32 = h->width == FHE_WIDTH_32 && !h->single_transforms && fhe_dev::lds_paired_keyswitch(4, (int)h->log_n);
+        if (((A.joint3 && h->width != FHE_WIDTH_32) || paired32) && !h->no_c2_compaction && !c2_in_ws2) {   // (c2 already in the workspace: the composed multiply + relinearise under a testing switch)
+            // Every limb workgroup re-reads all of c2 (the three-array kernels once per DIGIT): compact it once (a streaming pass: S read, S/4 or
+            // S/8 written) so that those re-reads move compact polynomials instead of 32-byte containers -- round 2 counters at N = 2^14, 6 x 40-bit:
+            // 2.6 x the algorithmic bytes; on the 4-byte residues the container loads kept the address FIFO full 12 % of the time (round 3 SQ counters).
+            // Chunks of whole ciphertexts on two streams: the compaction of chunk i+1 (HBM-bound) runs beside the key switch of chunk i.
+            if ((rc = ensure_ws2(h, (size_t)batch * Sc))) return rc;
+            // (measured, N = 8192 x 4 x 30-bit, batch 1024: compaction alone 773 K -> 805 K relin/s at w = 16, 948 K -> 1007 K at w = 30; with the key switch of
+            //  chunk i beside the compaction of chunk i+1 on a second stream 807 K / 953 K at two chunks, 772 K / 948 K at four: one stream unless asked)
+            uint32_t chunks = (paired32 && h->relin_chunks_forced) ? h->overlap_chunks : 1;
+            while (chunks > 1 && ((size_t)batch * h->L / chunks < 1024 || batch < chunks)) chunks--;
+            if (chunks > 1 && (rc = ensure_aux_stream(h))) return rc;
+            for (uint32_t c = 0, b0 = 0; c < chunks; c++) {
+                const uint32_t nb = batch / chunks + (c < batch % chunks ? 1 : 0);
+                char *c2c = (char *)h->d_ws2 + (size_t)b0 * Sc;
+                if ((rc = compact_poly(h, c2c, (const char *)d_c2 + (size_t)b0 * S, (size_t)nb * h->L * h->n))) return rc;
+                fhe_dev::LdsArgs B = A;
+                B.r0 = (char *)d_c0 + (size_t)b0 * S; B.r1 = (char *)d_c1 + (size_t)b0 * S; B.a0 = c2c; B.polys = nb * h->L; B.c2_only_compact = true;
+                if (chunks > 1) {
+                    HIP_TRY(hipEventRecord(h->ev_chunk[c], h->stream));
+                    HIP_TRY(hipStreamWaitEvent(h->aux_stream, h->ev_chunk[c], 0));
+                    B.stream = h->aux_stream;
+                }
+                fn(B);
+                if ((rc = post_launch(B.stream, "ntt_keyswitch_kernel"))) return rc;
+                b0 += nb;
+            }
+            if (chunks > 1) {
+                HIP_TRY(hipEventRecord(h->ev_join, h->aux_stream));
+                HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_join, 0));
+            }
+            return FHE_OK;
         }
         fn(A);
         return post_launch(h->stream, "ntt_keyswitch_kernel");
@@ -1262,11 +1298,7 @@ extern "C" int fhe_ct_multiply_relin(fhe_rns_ntt_t *h, const fhe_relin_keys_t *r
             if (bws && h->log_n >= 14) chunks = 1;               // 128+ KiB of LDS per workgroup: the two stages cannot share a CU anyway
         }
         while (chunks > 1 && (polys / chunks < 1024 || batch < chunks)) chunks--;   // every chunk must fill the chip: >= 256 CUs x 4 workgroups (one per limb polynomial)
-        if (chunks > 1 && !h->aux_stream) {
-            HIP_TRY(hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking));
-            HIP_TRY(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
-            for (hipEvent_t &e : h->ev_chunk) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        }
+        if (chunks > 1 && (rc = ensure_aux_stream(h))) return rc;
         const size_t S = (size_t)h->L * h->n * 32, Sc = (size_t)h->L * h->n * eb;   // bytes of one ciphertext component: containers / compact
         for (uint32_t c = 0, b0 = 0; c < chunks; c++) {
             const uint32_t nb = batch / chunks + (c < batch % chunks ? 1 : 0);

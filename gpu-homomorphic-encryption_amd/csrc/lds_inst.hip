@@ -144,9 +144,14 @@ void CAT(lds_launch_, FHE_FIELD, FHE_LOGN)(const LdsArgs &A) {
                     hipLaunchKernelGGL((ntt_keyswitch_kernel<F, LOGN, 2, true>), dim3(A.polys * 2), block, 0, A.stream, (char *)A.r0, (char *)A.r1,
                                        (const char *)A.a0, (const char *)A.r0, (const char *)A.r1, (const E *)A.kb, (const E *)A.ka, limbs, A.L, A.K, A.w);
             } else if (lds_paired_keyswitch(sizeof(E), LOGN) && !A.single_transforms) {
-                if constexpr (lds_paired_keyswitch(sizeof(E), LOGN))
+                if constexpr (lds_paired_keyswitch(sizeof(E), LOGN)) {
+                    if (A.c2_only_compact)   // stand-alone relinearisation: c2 compacted by the host first, addends are the caller's containers
+                        hipLaunchKernelGGL((ntt_keyswitch2_kernel<F, LOGN, 2, true, false>), grid, block, 0, A.stream, (char *)A.r0, (char *)A.r1,
+                                           (const char *)A.a0, (const char *)A.r0, (const char *)A.r1, (const E *)A.kb, (const E *)A.ka, limbs, A.L, A.K, A.w);
+                    else
                     hipLaunchKernelGGL((ntt_keyswitch2_kernel<F, LOGN, 2>), grid, block, 0, A.stream, (char *)A.r0, (char *)A.r1,
                                        (const char *)A.a0, (const char *)A.r0, (const char *)A.r1, (const E *)A.kb, (const E *)A.ka, limbs, A.L, A.K, A.w);
+                }
             } else {
                 if (lds_twiddles_in_lds(sizeof(E), LOGN) && !A.global_twiddles) {
                     if constexpr (lds_twiddles_in_lds(sizeof(E), LOGN))

@@ -1561,7 +1561,7 @@ __device__ __forceinline__ void finish_pair(typename F::E (&acc0)[32], typename 
     }
 }
 
-template <class F, int LOGN, int MINW = 1, bool COMPACT = false>
+template <class F, int LOGN, int MINW = 1, bool COMPACT = false, bool ADD_COMPACT = COMPACT>      // COMPACT: c2 is a compact polynomial; ADD_COMPACT: the addends are too
 __global__ void __launch_bounds__(NttCfg<LOGN>::T, MINW)
 ntt_keyswitch2_kernel(char *c0, char *c1, const char *__restrict__ c2, const char *add0, const char *add1,   // add* = c* (in place) unless COMPACT
                       const typename F::E *__restrict__ kb, const typename F::E *__restrict__ ka,
@@ -1616,7 +1616,7 @@ ntt_keyswitch2_kernel(char *c0, char *c1, const char *__restrict__ c2, const cha
         fwd_core<F, LOGN, false, true>(d0, lds, tid, P);
         mac_keys<F>(acc0, acc1, d0, kb, ka, ((size_t)jk * L + i) * C::N, tid, C::T, P);
     }
-    finish_pair<F, LOGN, COMPACT>(acc0, acc1, d0, d1, lds, tid, P, add0, add1, p, c0, c1);
+    finish_pair<F, LOGN, ADD_COMPACT>(acc0, acc1, d0, d1, lds, tid, P, add0, add1, p, c0, c1);
 }
 
 // IN_COMPACT / OUT_COMPACT: the accumulator pair is read from / written to compact polynomials (load_A_compact): inside fhe_blind_rotate

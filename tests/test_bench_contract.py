@@ -48,6 +48,9 @@ def test_default_workload_line_has_every_contract_field():
     x = {(e["prime_bits"], e["limbs"]): e for e in d["extra_width_classes"]}
     assert set(x) == {(40, 3), (60, 2), (64, 2), (128, 1), (250, 1)} and all("error" not in e and e["polymul_per_s"] > 0 for e in x.values())
     assert all(e["secondary"]["bound"] == "valu-int-mul" and 0 < e["secondary"]["frac"] < 1.2 for e in x.values())
+    w = d["extra_workloads"]                  # the other BASELINE configurations, each a short child run
+    assert len(w) == 6 and all("error" not in e and e["value"] > 0 and 0 < e["hbm_frac"] < 1 and e["int_mul_frac"] > 0 for e in w), w
+    assert w[0]["unit"] == "ct-mul/s" and w[0]["verified"] is True and w[4]["unit"] == "extprod/s"
     assert x[(250, 1)]["secondary"]["multiply_class_per_butterfly"] == 136 and x[(128, 1)]["secondary"]["multiply_class_per_butterfly"] == 136
     assert x[(250, 1)]["width_class"] == 4 and x[(40, 3)]["width_class"] == 3
 

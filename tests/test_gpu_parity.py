@@ -382,12 +382,16 @@ def test_relinearize_matches_oracle(eng, oracle, monkeypatch, n, spec, w, batch,
 
 
 @pytest.mark.parametrize("n,spec,w,batch", [(16384, ("bits", 40, 3), 16, 3), (8192, ("bits", 40, 3), 20, 9), (16384, ("bits", 60, 2), 32, 2),
-                                            (4096, ("bits", 64, 2), 32, 5), (8192, ("bits", 62, 1), 16, 2)])
-@pytest.mark.parametrize("compaction", [True, False])
-def test_relinearize_8_byte_fields_with_and_without_c2_compaction(eng, oracle, monkeypatch, n, spec, w, batch, compaction):
-    """Stand-alone relinearisation of the 8-byte fields: c2 is compacted once (compact_kernel) and the three-array kernel re-reads the
-    compact copy per digit; FHE_HIP_NO_C2_COMPACTION=1 keeps the container reads of round 2.  Both against the oracle; c2 is left untouched."""
-    if not compaction:
+                                            (4096, ("bits", 64, 2), 32, 5), (8192, ("bits", 62, 1), 16, 2),
+                                            (8192, ("bits", 30, 4), 16, 5), (16384, ("bits", 30, 3), 30, 2), (2048, ("bits", 30, 5), 8, 11)])
+@pytest.mark.parametrize("compaction", [True, False, "pipeline"])
+def test_relinearize_with_and_without_c2_compaction(eng, oracle, monkeypatch, n, spec, w, batch, compaction):
+    """Stand-alone relinearisation: c2 is compacted once (compact_kernel) and the key-switch kernel (three-array on the 8-byte fields, paired on the
+    4-byte one) re-reads the compact copy; FHE_HIP_NO_C2_COMPACTION=1 keeps the container reads of round 2; FHE_HIP_RELIN_PIPELINE=1 runs compaction
+    and key switch as a two-stream pipeline where the batch allows.  All against the oracle; c2 is left untouched."""
+    if compaction == "pipeline":
+        monkeypatch.setenv("FHE_HIP_RELIN_PIPELINE", "1")
+    elif not compaction:
         monkeypatch.setenv("FHE_HIP_NO_C2_COMPACTION", "1")
     moduli = _moduli(spec, n); L = len(moduli)
     e = eng.RnsNttEngine(n, moduli); rp = oracle.RnsPlan(n, moduli)
