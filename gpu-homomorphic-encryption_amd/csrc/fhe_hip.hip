@@ -247,6 +247,7 @@ struct fhe_rns_ntt {
     hipStream_t aux_stream = nullptr;   // second stream of the overlapped one-call multiply (fork / join with events around it)
     hipEvent_t ev_chunk[16] = {}, ev_join = nullptr;   // tensor product of chunk i done (engine stream) -> key switch of chunk i may start (second stream)
     uint32_t small_batch_polys = 256;   // FHE_HIP_SMALL_BATCH_POLYS: fused multiply of at most this many limb polynomials runs the 16-per-thread latency kernel (0 = never)
+    uint32_t split_pairs_polys = 64;    // FHE_HIP_SPLIT_PAIRS_POLYS: key switch (paired kernel) of at most this many limb polynomials runs one workgroup per digit pair + a combining launch (0 = never)
     bool relin_chunks_forced = false;   // FHE_HIP_RELIN_PIPELINE=1: the stand-alone relinearisation also runs as a two-stream pipeline (A/B)
     uint32_t overlap_chunks = 4;        // FHE_HIP_CT_RELIN_CHUNKS: pieces the one-call multiply is cut into (1 = one stream, as in round 2)
     void *d_limbs = nullptr;            // owned by d_tables
@@ -543,6 +544,7 @@ static int create_impl(fhe_rns_ntt **out, uint32_t n, const uint64_t (*moduli)[4
     h->no_two_launch_ct = getenv("FHE_HIP_NO_TWO_LAUNCH_CT") != nullptr;
     h->split_keyswitch = getenv("FHE_HIP_SPLIT_KEYSWITCH") != nullptr;
     if (const char *m = getenv("FHE_HIP_SMALL_BATCH_POLYS")) { const long v = atol(m); h->small_batch_polys = v < 0 ? 0u : (uint32_t)v; }
+    if (const char *m = getenv("FHE_HIP_SPLIT_PAIRS_POLYS")) { const long v = atol(m); h->split_pairs_polys = v < 0 ? 0u : (uint32_t)v; }
     h->relin_chunks_forced = getenv("FHE_HIP_RELIN_PIPELINE") != nullptr;
     if (const char *m = getenv("FHE_HIP_CT_RELIN_CHUNKS")) { const int v = atoi(m); h->overlap_chunks = v < 1 ? 1 : v > 16 ? 16 : (uint32_t)v; }
     h->no_prerotation = getenv("FHE_HIP_NO_PREROTATION") != nullptr;       // blind-rotation loop of the three-array kernels: monomial factor inside the kernel, per digit (A/B, cross-check)
@@ -715,6 +717,16 @@ static int big_inverse(fhe_rns_ntt *h, void *data, uint32_t polys) {
     int rc = ensure_ws3(h, (size_t)polys * h->n * residue_bytes(h)); if (rc) return rc;
     if ((rc = lds_big(h, fhe_dev::LDS_SUB_INVERSE, h->d_ws3, true, data, false, nullptr, polys, false, "ntt_sub_kernel"))) return rc;
     return lds_big(h, fhe_dev::LDS_PASS_INV, data, false, h->d_ws3, true, nullptr, polys, false, "word_pass_kernel");
+}
+
+// Few ciphertexts on the paired key-switch kernel: one workgroup per digit pair and a combining launch (ntt_lds_small.hip.h) -- sets A.pair_ws.
+static int split_pairs_workspace(fhe_rns_ntt *h, fhe_dev::LdsArgs &A) {
+    if (h->width != FHE_WIDTH_32 || h->single_transforms || !fhe_dev::lds_paired_keyswitch(4, (int)h->log_n)) return FHE_OK;
+    const uint32_t NP = (h->L * A.K + 1) / 2;
+    if (NP < 2 || A.polys > h->split_pairs_polys) return FHE_OK;
+    int rc = ensure_ws(h, 2 * (size_t)A.polys * NP * h->n * 4); if (rc) return rc;
+    A.pair_ws = h->d_ws;
+    return FHE_OK;
 }
 
 // Key switch / external product of the 8-byte residues (and of the 4-byte residues at N = 2^15): ONE workgroup per (ciphertext, limb)
@@ -1216,6 +1228,7 @@ extern "C" int fhe_ct_relinearize(fhe_rns_ntt_t *h, const fhe_relin_keys_t *rk, 
                 if ((rc = compact_poly(h, c2c, (const char *)d_c2 + (size_t)b0 * S, (size_t)nb * h->L * h->n))) return rc;
                 fhe_dev::LdsArgs B = A;
                 B.r0 = (char *)d_c0 + (size_t)b0 * S; B.r1 = (char *)d_c1 + (size_t)b0 * S; B.a0 = c2c; B.polys = nb * h->L; B.c2_only_compact = true;
+                if (chunks == 1 && (rc = split_pairs_workspace(h, B))) return rc;
                 if (chunks > 1) {
                     HIP_TRY(hipEventRecord(h->ev_chunk[c], h->stream));
                     HIP_TRY(hipStreamWaitEvent(h->aux_stream, h->ev_chunk[c], 0));
@@ -1231,6 +1244,7 @@ extern "C" int fhe_ct_relinearize(fhe_rns_ntt_t *h, const fhe_relin_keys_t *rk, 
             }
             return FHE_OK;
         }
+        if ((rc = split_pairs_workspace(h, A))) return rc;
         fn(A);
         return post_launch(h->stream, "ntt_keyswitch_kernel");
     }
@@ -1307,6 +1321,7 @@ extern "C" int fhe_ct_multiply_relin(fhe_rns_ntt_t *h, const fhe_relin_keys_t *r
                                (const char *)d_b1 + o, h->d_limbs, h->L, nb * h->L, h->stream};
             A.compact_c2 = true;
             if (bws) A.ws = bws + 2 * oc;                        // two compact polynomials per limb polynomial of the chunk
+            A.small_batch = A.polys <= h->split_pairs_polys;     // few ciphertexts: the 16-per-thread tensor product (and, below, the split key switch)
             fn(A);
             if ((rc = post_launch(h->stream, "tensor product (compact outputs)"))) return rc;
             hipStream_t ks = h->stream;
@@ -1318,6 +1333,7 @@ extern "C" int fhe_ct_multiply_relin(fhe_rns_ntt_t *h, const fhe_relin_keys_t *r
             fhe_dev::LdsArgs B{fhe_dev::LDS_KEYSWITCH, (char *)d_c0 + o, (char *)d_c1 + o, nullptr, c2c + oc, c0c + oc, c1c + oc, nullptr, h->d_limbs, h->L, nb * h->L, ks};
             B.kb = rk->d_pkb; B.ka = rk->d_pka; B.K = rk->K; B.w = rk->decomp_bits; B.compact_c2 = true;
             B.joint3 = use_joint3(h, false, true);
+            if (chunks == 1 && !bws && (rc = split_pairs_workspace(h, B))) return rc;     // (d_ws is free: no two-launch tensor product on the 4-byte field up to 2^14)
             fn(B);
             if ((rc = post_launch(ks, "key switch (compact operands)"))) return rc;
             b0 += nb;

@@ -21,6 +21,43 @@ static bool launch_small_multiply(const LdsArgs &A, const Limb<F> *limbs) {
     }
 }
 
+// tensor product with compact outputs for few ciphertexts (the first half of the one-call multiply + relinearise)
+template <class F, int LOGN>
+static bool launch_small_ct_multiply(const LdsArgs &A, const Limb<F> *limbs) {
+    using E = typename F::E;
+    if constexpr (lds_small_multiply(sizeof(E), LOGN)) {
+        hipLaunchKernelGGL((ntt16_ct_multiply_kernel<F, LOGN>), dim3(A.polys), dim3(Cfg16<LOGN>::T), 0, A.stream, (E *)A.r0, (E *)A.r1, (E *)A.r2,
+                           (const char *)A.a0, (const char *)A.a1, (const char *)A.b0, (const char *)A.b1, limbs, A.L);
+        return true;
+    } else {
+        return false;
+    }
+}
+// key switch of few ciphertexts: one workgroup per digit pair + a combining launch (ntt_lds_small.hip.h), where the paired kernel exists
+template <class F, int LOGN>
+static bool launch_split_keyswitch(const LdsArgs &A, const Limb<F> *limbs) {
+    using E = typename F::E;
+    if constexpr (lds_paired_keyswitch(sizeof(E), LOGN)) {
+        const uint32_t NP = (A.L * A.K + 1) / 2;
+        const dim3 block(NttCfg<LOGN>::T), pgrid(A.polys * NP), cgrid(A.polys);
+        E *part0 = (E *)A.pair_ws, *part1 = part0 + (size_t)A.polys * NP * (1u << LOGN);
+        const bool c2_compact = A.compact_c2 || A.c2_only_compact;
+        if (c2_compact)
+            hipLaunchKernelGGL((ntt_keyswitch2_part_kernel<F, LOGN, true>), pgrid, block, 0, A.stream, part0, part1, (const char *)A.a0, (const E *)A.kb, (const E *)A.ka, limbs, A.L, A.K, A.w);
+        else
+            hipLaunchKernelGGL((ntt_keyswitch2_part_kernel<F, LOGN, false>), pgrid, block, 0, A.stream, part0, part1, (const char *)A.a0, (const E *)A.kb, (const E *)A.ka, limbs, A.L, A.K, A.w);
+        if (A.compact_c2)    // fused multiply + relinearise: the addends are the compact c0 (a1) and c1 (b0)
+            hipLaunchKernelGGL((ntt_keyswitch2_comb_kernel<F, LOGN, true>), cgrid, block, 0, A.stream, (char *)A.r0, (char *)A.r1, (const E *)part0, (const E *)part1,
+                               (const char *)A.a1, (const char *)A.b0, limbs, A.L, A.K);
+        else                 // in place on the caller's containers
+            hipLaunchKernelGGL((ntt_keyswitch2_comb_kernel<F, LOGN, false>), cgrid, block, 0, A.stream, (char *)A.r0, (char *)A.r1, (const E *)part0, (const E *)part1,
+                               (const char *)A.r0, (const char *)A.r1, limbs, A.L, A.K);
+        return true;
+    } else {
+        return false;
+    }
+}
+
 void CAT(lds_launch_, FHE_FIELD, FHE_LOGN)(const LdsArgs &A) {
     using F = FHE_FIELD;
     constexpr int LOGN = FHE_LOGN;
@@ -71,6 +108,7 @@ void CAT(lds_launch_, FHE_FIELD, FHE_LOGN)(const LdsArgs &A) {
                                    (const char *)A.b0, limbs, A.L, A.b_polys ? 1u : 0u);
             break;
         case LDS_CT_MULTIPLY:
+            if (A.small_batch && A.compact_c2 && !A.ws && launch_small_ct_multiply<F, LOGN>(A, limbs)) break;   // few ciphertexts (ntt_lds_small.hip.h)
             if (A.ws) {                  // two launches: the b-side transforms into the workspace, then one workgroup per (ciphertext, limb) does the rest
                 if constexpr (lds_ct_two_launch(sizeof(typename F::E), LOGN)) {
                     using E = typename F::E;
@@ -115,6 +153,7 @@ void CAT(lds_launch_, FHE_FIELD, FHE_LOGN)(const LdsArgs &A) {
             break;
         case LDS_KEYSWITCH: {
             using E = typename F::E;
+            if (A.pair_ws && !A.single_transforms && !A.joint3 && launch_split_keyswitch<F, LOGN>(A, limbs)) break;   // few ciphertexts
             if (A.compact_c2) {          // the host sets it only where lds_compact_c2 holds and the default kernels are selected
                 if constexpr (lds_compact_c2(sizeof(E), LOGN)) {
                     if constexpr (lds_keyswitch_split(sizeof(E), LOGN)) {

@@ -287,4 +287,127 @@ ntt16_multiply_kernel(char *res, const char *a, const char *b, const Limb<F> *__
     STAMP(6);
 }
 
+// Tensor product of FHEContext::multiply (src/fhe.cu:199-218) for few ciphertexts, outputs as COMPACT polynomials (the first half of the
+// one-call multiply + relinearise): c0 = a0 b0, c1 = a0 b1 + a1 b0, c2 = a1 b1.  Same latency argument as ntt16_multiply_kernel: twice the waves of
+// the 32-per-thread kernel on the same polynomial, every twiddle loaded once at the top beside the four operands.
+template <class F, int LOGN>
+__global__ void __launch_bounds__(Cfg16<LOGN>::T)
+ntt16_ct_multiply_kernel(typename F::E *__restrict__ c0, typename F::E *__restrict__ c1, typename F::E *__restrict__ c2,
+                         const char *__restrict__ a0, const char *__restrict__ a1, const char *__restrict__ b0, const char *__restrict__ b1,
+                         const Limb<F> *__restrict__ limbs, uint32_t L) {
+    using C = Cfg16<LOGN>;
+    using E = typename F::E;
+    __shared__ E lds[C::N];
+    const uint32_t tid = threadIdx.x, p = blockIdx.x;
+    const Limb<F> P = limbs[p % L];
+    const size_t off = (size_t)p * (C::N * 32), offc = (size_t)p * C::N;
+    E A0[16], A1[16], B0[16], B1[16];
+    Twiddles16<F, LOGN> W;
+    W.load(tid, P);
+    load16<F, LOGN>(a0 + off, tid, A0);
+    load16<F, LOGN>(a1 + off, tid, A1);
+    load16<F, LOGN>(b0 + off, tid, B0);
+    load16<F, LOGN>(b1 + off, tid, B1);
+    fwd_core16<F, LOGN>(A0, lds, tid, P, W);
+    __syncthreads();
+    fwd_core16<F, LOGN>(A1, lds, tid, P, W);
+    __syncthreads();
+    fwd_core16<F, LOGN>(B0, lds, tid, P, W);
+    __syncthreads();
+    fwd_core16<F, LOGN>(B1, lds, tid, P, W);
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const E u0 = F::canon_fwd(A0[r], P.q, P.q2, P.qinv), u1 = F::canon_fwd(A1[r], P.q, P.q2, P.qinv);   // canonical a-side
+        const E v0 = B0[r], v1 = B1[r];                                                                     // lazy b-side
+        A0[r] = F::pw_mul(u0, v0, P.q, P.qinv);
+        A1[r] = F::pw_mul2(u0, v1, u1, v0, P.q, P.q2, P.qinv);
+        B0[r] = F::pw_mul(u1, v1, P.q, P.qinv);
+    }
+    // three inverse transforms; each result leaves in pattern A = natural order of a compact polynomial (index tid + r T)
+    inv_core16<F, LOGN>(A0, lds, tid, P, W, P.ninv_r, P.ninv_r_s, P.ninvw_r, P.ninvw_r_s);
+#pragma unroll
+    for (int r = 0; r < 16; r++) c0[offc + tid + (size_t)r * C::T] = F::canon_inv(A0[r], P.q);
+    __syncthreads();
+    inv_core16<F, LOGN>(A1, lds, tid, P, W, P.ninv_r, P.ninv_r_s, P.ninvw_r, P.ninvw_r_s);
+#pragma unroll
+    for (int r = 0; r < 16; r++) c1[offc + tid + (size_t)r * C::T] = F::canon_inv(A1[r], P.q);
+    __syncthreads();
+    inv_core16<F, LOGN>(B0, lds, tid, P, W, P.ninv_r, P.ninv_r_s, P.ninvw_r, P.ninvw_r_s);
+#pragma unroll
+    for (int r = 0; r < 16; r++) c2[offc + tid + (size_t)r * C::T] = F::canon_inv(B0[r], P.q);
+}
+
+// ---- key switching for few ciphertexts: the digit pairs of a limb go to SEPARATE workgroups ------------------------------------------
+// ntt_keyswitch2_kernel runs all ceil(L K / 2) paired digit transforms of a (ciphertext, limb) one after the other in one workgroup --
+// right for throughput, but with fewer workgroups than CUs the call lasts as long as that one workgroup (55 us at N = 8192, L = 4,
+// w = 16: five paired transforms at one wave per SIMD).  Here a first launch gives every (ciphertext, limb, digit pair) its own workgroup:
+// paired forward transform and the key products of that pair only, the two NTT-domain partial accumulators (values in [0, 2q)) written in
+// register order to a workspace (slot tid + r T); a second launch sums the partials of a (ciphertext, limb) and finishes as the one-launch
+// kernel does (paired inverse transform, addends, store).  Same arithmetic in the same order within a pair, and the sums of lazy values
+// are reduced exactly as the running accumulators are (pw_add), so the containers are bit-identical.
+template <class F, int LOGN, bool COMPACT>
+__global__ void __launch_bounds__(NttCfg<LOGN>::T, 2)
+ntt_keyswitch2_part_kernel(typename F::E *__restrict__ part0, typename F::E *__restrict__ part1, const char *__restrict__ c2,
+                           const typename F::E *__restrict__ kb, const typename F::E *__restrict__ ka,
+                           const Limb<F> *__restrict__ limbs, uint32_t L, uint32_t K, uint32_t w) {
+    using C = NttCfg<LOGN>;
+    using E = typename F::E;
+    __shared__ E lds[2 * C::LDS_ELEMS];
+    const uint32_t LK = L * K, NP = (LK + 1) / 2;
+    const uint32_t tid = threadIdx.x, pr = blockIdx.x % NP, p = blockIdx.x / NP, b = p / L, i = p % L;     // p = ciphertext * L + limb
+    const Limb<F> P = limbs[i];
+    const TableBuf C2(c2 + (size_t)b * L * (C::N * (COMPACT ? sizeof(E) : 32)));
+    E acc0[32], acc1[32], d0[32], d1[32];
+#pragma unroll
+    for (int r = 0; r < 32; r++) { acc0[r] = 0; acc1[r] = 0; }
+    const uint32_t jk = 2 * pr;
+    if (jk + 1 < LK) {
+        const uint32_t j0 = jk / K, k0 = jk % K, j1 = (jk + 1) / K, k1 = (jk + 1) % K;
+        load_src_buf<F, LOGN, COMPACT>(C2, j1, tid, d1);
+        if (j0 == j1) {
+#pragma unroll
+            for (int r = 0; r < 32; r++) d0[r] = F::digit(d1[r], k0 * w, w);
+        } else {
+            load_src_buf<F, LOGN, COMPACT>(C2, j0, tid, d0);
+#pragma unroll
+            for (int r = 0; r < 32; r++) d0[r] = F::digit(d0[r], k0 * w, w);
+        }
+#pragma unroll
+        for (int r = 0; r < 32; r++) d1[r] = F::digit(d1[r], k1 * w, w);
+        fwd_core2<F, LOGN, false>(d0, d1, lds, tid, P);
+        mac_keys2<F, true>(acc0, acc1, d0, d1, kb, ka, ((size_t)jk * L + i) * C::N, kb, ka, ((size_t)(jk + 1) * L + i) * C::N, tid, C::T, P);
+    } else {                                              // odd number of digit polynomials: the last one alone
+        const uint32_t j0 = jk / K, k0 = jk % K;
+        load_src_buf<F, LOGN, COMPACT>(C2, j0, tid, d0);
+#pragma unroll
+        for (int r = 0; r < 32; r++) d0[r] = F::digit(d0[r], k0 * w, w);
+        fwd_core<F, LOGN>(d0, lds, tid, P);
+        mac_keys<F>(acc0, acc1, d0, kb, ka, ((size_t)jk * L + i) * C::N, tid, C::T, P);
+    }
+    const size_t slot = ((size_t)p * NP + pr) * C::N;
+    store_A_compact<F, LOGN>(part0 + slot, tid, acc0);    // register order: the combining launch reads slot tid + r T back into register r
+    store_A_compact<F, LOGN>(part1 + slot, tid, acc1);
+}
+template <class F, int LOGN, bool ADD_COMPACT>
+__global__ void __launch_bounds__(NttCfg<LOGN>::T, 2)
+ntt_keyswitch2_comb_kernel(char *c0, char *c1, const typename F::E *__restrict__ part0, const typename F::E *__restrict__ part1,
+                           const char *add0, const char *add1, const Limb<F> *__restrict__ limbs, uint32_t L, uint32_t K) {
+    using C = NttCfg<LOGN>;
+    using E = typename F::E;
+    __shared__ E lds[2 * C::LDS_ELEMS];
+    const uint32_t NP = (L * K + 1) / 2;
+    const uint32_t tid = threadIdx.x, p = blockIdx.x, i = p % L;
+    const Limb<F> P = limbs[i];
+    E acc0[32], acc1[32], t0[32], t1[32];
+    load_A_compact<F, LOGN>(part0 + (size_t)p * NP * C::N, tid, acc0);
+    load_A_compact<F, LOGN>(part1 + (size_t)p * NP * C::N, tid, acc1);
+    for (uint32_t pr = 1; pr < NP; pr++) {                // the order in which the one-launch kernel accumulates its pairs
+        load_A_compact<F, LOGN>(part0 + ((size_t)p * NP + pr) * C::N, tid, t0);
+        load_A_compact<F, LOGN>(part1 + ((size_t)p * NP + pr) * C::N, tid, t1);
+#pragma unroll
+        for (int r = 0; r < 32; r++) { acc0[r] = F::pw_add(acc0[r], t0[r], P.q, P.q2); acc1[r] = F::pw_add(acc1[r], t1[r], P.q, P.q2); }
+    }
+    finish_pair<F, LOGN, ADD_COMPACT>(acc0, acc1, t0, t1, lds, tid, P, add0, add1, p, c0, c1);
+}
+
 }  // namespace fhe_dev

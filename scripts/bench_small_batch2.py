@@ -28,3 +28,26 @@ for B in BATCHES:
         us = t.elapsed_ms() * 1e3 / steps
         line = {"op": "multiply", "n": n, "limbs": L, "batch": B, "kernel": name, "us_per_call": us, "polymul_per_s": B / (us * 1e-6)}
         out.write(json.dumps(line) + "\n"); print(line, flush=True)
+
+# full ciphertext multiply (configs[2]) at small batches: digit pairs of the key switch on separate workgroups (default below 256 limb polynomials) vs the one-launch kernel
+def engine2(split):
+    os.environ["FHE_HIP_SPLIT_PAIRS_POLYS"] = str(split)
+    try: return pkg.RnsNttEngine(n, moduli)
+    finally: os.environ.pop("FHE_HIP_SPLIT_PAIRS_POLYS", None)
+engs2 = {"split-pairs": engine2(1000000), "one-launch": engine2(0)}
+w = 16
+for B in BATCHES:
+    ops = [pkg.DeviceBuffer.from_numpy(rns_poly(10 + i, moduli, n, B)) for i in range(4)]
+    o0, o1 = pkg.DeviceBuffer(B * L * n * 32), pkg.DeviceBuffer(B * L * n * 32)
+    for name, e in engs2.items():
+        K = e.relin_num_digits(w)
+        keys = [[pkg.DeviceBuffer.from_numpy(rns_poly(7000 + 31 * i + 997 * h, moduli, n, 1)) for i in range(L * K)] for h in range(2)]
+        rk = e.import_relin_keys(w, keys[0], keys[1])
+        for _ in range(10): e.ct_multiply_relin(rk, o0, o1, ops[0], ops[1], ops[2], ops[3], B)
+        pkg.capi.sync(); t = pkg.Timer(); steps = 200
+        t.start(e)
+        for _ in range(steps): e.ct_multiply_relin(rk, o0, o1, ops[0], ops[1], ops[2], ops[3], B)
+        t.stop(e); pkg.capi.sync()
+        us = t.elapsed_ms() * 1e3 / steps
+        line = {"op": "ctrelin", "n": n, "limbs": L, "w": w, "batch": B, "kernel": name, "us_per_call": us, "ct_mul_per_s": B / (us * 1e-6)}
+        out.write(json.dumps(line) + "\n"); print(line, flush=True)

@@ -146,7 +146,7 @@ def test_forward_inverse_multiply_match_oracle(eng, oracle, monkeypatch, n, spec
     want_mul = rp.polymul(a, b, threads=8)
     assert np.array_equal(dR.download(shape), want_mul)
     assert np.array_equal(dA.download(shape), a) and np.array_equal(dB.download(shape), b)
-    if width == eng.WIDTH_32 and n <= 16384:
+    if width == eng.WIDTH_32 and n <= 8192:
         # few polynomials run the 16-per-thread latency kernel (ntt_lds_small.hip.h) by default: the throughput kernel on the same operands,
         # and the latency kernel forced for any batch, must give the same containers
         for polys in ("0", "1000000"):
@@ -384,13 +384,17 @@ def test_relinearize_matches_oracle(eng, oracle, monkeypatch, n, spec, w, batch,
 @pytest.mark.parametrize("n,spec,w,batch", [(16384, ("bits", 40, 3), 16, 3), (8192, ("bits", 40, 3), 20, 9), (16384, ("bits", 60, 2), 32, 2),
                                             (4096, ("bits", 64, 2), 32, 5), (8192, ("bits", 62, 1), 16, 2),
                                             (8192, ("bits", 30, 4), 16, 5), (16384, ("bits", 30, 3), 30, 2), (2048, ("bits", 30, 5), 8, 11)])
-@pytest.mark.parametrize("compaction", [True, False, "pipeline"])
+@pytest.mark.parametrize("compaction", [True, False, "pipeline", "one-launch", "one-launch-containers"])
 def test_relinearize_with_and_without_c2_compaction(eng, oracle, monkeypatch, n, spec, w, batch, compaction):
     """Stand-alone relinearisation: c2 is compacted once (compact_kernel) and the key-switch kernel (three-array on the 8-byte fields, paired on the
     4-byte one) re-reads the compact copy; FHE_HIP_NO_C2_COMPACTION=1 keeps the container reads of round 2; FHE_HIP_RELIN_PIPELINE=1 runs compaction
     and key switch as a two-stream pipeline where the batch allows.  All against the oracle; c2 is left untouched."""
     if compaction == "pipeline":
         monkeypatch.setenv("FHE_HIP_RELIN_PIPELINE", "1")
+    elif compaction in ("one-launch", "one-launch-containers"):   # the throughput form of the paired key switch (few ciphertexts split its digit pairs by default)
+        monkeypatch.setenv("FHE_HIP_SPLIT_PAIRS_POLYS", "0")
+        if compaction == "one-launch-containers":
+            monkeypatch.setenv("FHE_HIP_NO_C2_COMPACTION", "1")
     elif not compaction:
         monkeypatch.setenv("FHE_HIP_NO_C2_COMPACTION", "1")
     moduli = _moduli(spec, n); L = len(moduli)
@@ -1308,12 +1312,14 @@ def test_check_inputs_switch_rejects_noncanonical_operands(eng, monkeypatch, bit
                                             (4096, ("bits", 40, 2), 20, 3), (8192, ("bits", 43, 2), 16, 1), (16384, ("bits", 40, 2), 20, 1),
                                             (2048, ("bits", 60, 2), 32, 2), (8192, ("bits", 64, 1), 32, 1), (256, ("bits", 250, 1), 64, 2),
                                             (2048, ("bits", 120, 1), 40, 1)])
-@pytest.mark.parametrize("fused", [True, False])
+@pytest.mark.parametrize("fused", [True, False, "one-launch-keyswitch"])
 def test_ct_multiply_relin_matches_oracle(eng, oracle, monkeypatch, n, spec, w, batch, fused):
     """FHEContext::multiply as the reference declares it (src/fhe.cu:199-224): tensor product + relinearisation in ONE call.  fused: c2
     crosses from the tensor-product kernel to the key-switch kernel in the compact workspace where both kernels exist (else, and with
     FHE_HIP_NO_FUSED_CT_RELIN=1, the two-call composition inside the library); every variant equals oracle ct_multiply + relinearize."""
-    if not fused:
+    if fused == "one-launch-keyswitch":   # few ciphertexts split the digit pairs of the paired key switch over workgroups by default: here the throughput form
+        monkeypatch.setenv("FHE_HIP_SPLIT_PAIRS_POLYS", "0")
+    elif not fused:
         monkeypatch.setenv("FHE_HIP_NO_FUSED_CT_RELIN", "1")
     moduli = _moduli(spec, n); L = len(moduli)
     e = eng.RnsNttEngine(n, moduli); rp = oracle.RnsPlan(n, moduli)

@@ -100,14 +100,18 @@ def test_small_batch_latency_kernel(resources):
     kernels, _ = resources[("F32", 13)]
     for k in _all(kernels, "ntt16_multiply_kernel", 1):
         assert k["spill"] == 0 and k.get("scratch", 0) == 0 and k["vgprs"] <= 256 and k["occupancy"] >= 2 and k["lds"] == 32768, k
-    kernels14, _ = resources[("F32", 14)]
-    for k in _all(kernels14, "ntt16_multiply_kernel", 1):        # 1024 threads: 128 VGPRs per lane
-        assert k["vgprs"] <= 128 and k.get("scratch", 0) <= 256 and k["lds"] == 65536, k
+    for k in _all(kernels, "ntt16_ct_multiply_kernel", 1):       # the tensor product of few ciphertexts: four 16-entry arrays + 90 twiddles
+        assert k["spill"] == 0 and k.get("scratch", 0) == 0 and k["vgprs"] <= 256 and k["occupancy"] >= 2 and k["lds"] == 32768, k
+    for name in ("ntt_keyswitch2_part_kernel", "ntt_keyswitch2_comb_kernel"):   # key switch of few ciphertexts: one workgroup per digit pair + combine
+        for k in _all(kernels, name, 2):
+            assert k["spill"] == 0 and k.get("scratch", 0) == 0 and k["vgprs"] <= 256 and k["occupancy"] >= 2 and k["lds"] == 2 * 33792, (name, k)
+    kernels14, _ = resources[("F32", 14)]                        # N = 2^14 would be 1024 threads at 128 VGPRs (the preloaded twiddles spill): not instantiated
+    assert not [k for k in kernels14 if "ntt16_" in k]
 
 
 def test_compute_bound_kernels_do_not_spill(resources):
     kernels, _ = resources[("F32", 13)]
-    for name, variants, lds in (("ntt_ct_multiply_kernel", 3, 33792), ("ntt_keyswitch2_kernel", 2, 2 * 33792), ("ntt_extprod2_kernel", 4, 2 * 33792)):
+    for name, variants, lds in (("ntt_ct_multiply_kernel", 3, 33792), ("ntt_keyswitch2_kernel", 3, 2 * 33792), ("ntt_extprod2_kernel", 4, 2 * 33792)):
         for k in _all(kernels, name, variants):
             assert k["spill"] == 0 and k.get("scratch", 0) == 0, (name, k)
             assert k["vgprs"] <= 256 and k["occupancy"] >= 2, (name, k)    # 2 waves per SIMD = 2 workgroups per CU
