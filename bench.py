@@ -114,6 +114,8 @@ def parse():
     ap.add_argument("--timeout", type=float, default=float(os.environ.get("FHE_BENCH_TIMEOUT", "1500")),
                     help="self-launched ranks (--gpus N without a launcher): kill every rank and exit non-zero after this many seconds")
     ap.add_argument("--no-verify", action="store_true", help="skip the per-rank result checksum / oracle spot check (outside the timed region)")
+    ap.add_argument("--no-extra-workloads", action="store_true",
+                    help="skip the child runs of the other BASELINE configurations (profiling scripts pass it: children would add their own counter files)")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the extra legs (op multiply only): batched forward+inverse NTT pairs (the figure the north-star's >= 60 %% target is stated on) "
                          "and the small runs on the other modulus widths")
@@ -602,7 +604,7 @@ def main():
     out["dist_backend"] = None if dist is None else (args.dist_backend + (" (RCCL over xGMI)" if args.dist_backend == "nccl" else " (CPU rehearsal)"))
     if rank == 0 and world == 1 and not args.no_extras and args.op == "multiply":
         out["extra_width_classes"] = extra_width_classes(pkg)
-    if rank == 0 and world == 1 and not args.no_extras and args.op == "multiply" and args.shard == "batch":
+    if rank == 0 and world == 1 and not args.no_extras and not args.no_extra_workloads and args.op == "multiply" and args.shard == "batch":
         out["extra_workloads"] = extra_workloads()
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.op == "multiply":
         out["cpu_baseline"] = cpu_baseline(n, moduli)

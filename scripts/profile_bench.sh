@@ -9,12 +9,12 @@ shift || true
 EXTRA="$*"
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
-mkdir -p "$OUT"
+rm -rf "$OUT"; mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd "$ROOT"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline $EXTRA > "$OUT/bench_trace.log" 2>&1 \
- && rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline $EXTRA > "$OUT/bench_pmc_fetch.log" 2>&1 \
- && rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline $EXTRA > "$OUT/bench_pmc_write.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extra-workloads $EXTRA > "$OUT/bench_trace.log" 2>&1 \
+ && rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra-workloads $EXTRA > "$OUT/bench_pmc_fetch.log" 2>&1 \
+ && rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra-workloads $EXTRA > "$OUT/bench_pmc_write.log" 2>&1
 echo "profile rc=$?"
 find "$OUT" -name "*.csv" | head -20
 # keep the merge-back small: the per-dispatch traces are summarised, large raw files dropped

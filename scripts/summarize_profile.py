@@ -18,8 +18,9 @@ os.makedirs("profiles", exist_ok=True)
 
 
 def one(pattern):
-    fs = sorted(glob.glob(os.path.join(src, pattern)))
-    return fs[0] if fs else None
+    """the largest match (a profiled program that starts children leaves one file per process: the main process's is the big one)"""
+    fs = sorted(glob.glob(os.path.join(src, pattern)), key=os.path.getsize)
+    return fs[-1] if fs else None
 
 
 summary = {"tag": tag, "kernels": {}}
