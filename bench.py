@@ -297,7 +297,7 @@ def extra_workloads():
     out = []
     for name, extra in specs:
         try:
-            args = [sys.executable, os.path.abspath(__file__), "--no-extras", "--no-cpu-baseline", "--steps", "5", "--warmup", "1"] + extra
+            args = [sys.executable, os.path.abspath(__file__), "--no-extras", "--no-cpu-baseline", "--steps", "10", "--warmup", "3"] + extra
             res = subprocess.run(args, capture_output=True, text=True, timeout=300)
             d = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][0])
             r = d["roofline"]
