@@ -247,6 +247,7 @@ struct fhe_rns_ntt {
     hipStream_t aux_stream = nullptr;   // second stream of the overlapped one-call multiply (fork / join with events around it)
     hipEvent_t ev_chunk[16] = {}, ev_join = nullptr;   // tensor product of chunk i done (engine stream) -> key switch of chunk i may start (second stream)
     uint32_t small_batch_polys = 256;   // FHE_HIP_SMALL_BATCH_POLYS: fused multiply of at most this many limb polynomials runs the 16-per-thread latency kernel (0 = never)
+    uint32_t coop_polys = 64;           // FHE_HIP_COOP_POLYS: fused multiply of at most this many limb polynomials (N = 2^13 / 2^14, 4-byte residues) spreads each over four workgroups in three launches (0 = never)
     uint32_t split_pairs_polys = 64;    // FHE_HIP_SPLIT_PAIRS_POLYS: key switch (paired kernel) of at most this many limb polynomials runs one workgroup per digit pair + a combining launch (0 = never)
     bool relin_chunks_forced = false;   // FHE_HIP_RELIN_PIPELINE=1: the stand-alone relinearisation also runs as a two-stream pipeline (A/B)
     uint32_t overlap_chunks = 4;        // FHE_HIP_CT_RELIN_CHUNKS: pieces the one-call multiply is cut into (1 = one stream, as in round 2)
@@ -544,6 +545,7 @@ static int create_impl(fhe_rns_ntt **out, uint32_t n, const uint64_t (*moduli)[4
     h->no_two_launch_ct = getenv("FHE_HIP_NO_TWO_LAUNCH_CT") != nullptr;
     h->split_keyswitch = getenv("FHE_HIP_SPLIT_KEYSWITCH") != nullptr;
     if (const char *m = getenv("FHE_HIP_SMALL_BATCH_POLYS")) { const long v = atol(m); h->small_batch_polys = v < 0 ? 0u : (uint32_t)v; }
+    if (const char *m = getenv("FHE_HIP_COOP_POLYS")) { const long v = atol(m); h->coop_polys = v < 0 ? 0u : v > 64 ? 64u : (uint32_t)v; }
     if (const char *m = getenv("FHE_HIP_SPLIT_PAIRS_POLYS")) { const long v = atol(m); h->split_pairs_polys = v < 0 ? 0u : (uint32_t)v; }
     h->relin_chunks_forced = getenv("FHE_HIP_RELIN_PIPELINE") != nullptr;
     if (const char *m = getenv("FHE_HIP_CT_RELIN_CHUNKS")) { const int v = atoi(m); h->overlap_chunks = v < 1 ? 1 : v > 16 ? 16 : (uint32_t)v; }
@@ -768,6 +770,11 @@ static int lds_run(fhe_rns_ntt *h, int op, void *r0, void *r1, void *r2, const v
     A.single_transforms = h->single_transforms;
     A.b_polys = b_polys;
     A.small_batch = op == fhe_dev::LDS_MULTIPLY && polys <= h->small_batch_polys;
+    if (op == fhe_dev::LDS_MULTIPLY && polys <= h->coop_polys && fhe_dev::lds_coop4_multiply(h->width == FHE_WIDTH_32 ? 4 : 8, (int)h->log_n)) {
+        // (in place is fine: every operand container is read by the first launch, the result containers are written by the third)
+        int rc = ensure_ws3(h, 3 * (size_t)polys * h->n * 4); if (rc) return rc;
+        A.coop_ws = h->d_ws3;
+    }
     A.square = !b_polys && !h->no_square &&
                ((op == fhe_dev::LDS_MULTIPLY && a0 == b0) || (op == fhe_dev::LDS_CT_MULTIPLY && a0 == b0 && a1 == b1));
     if (op == fhe_dev::LDS_CT_MULTIPLY) { int rc = ct_workspace(h, A); if (rc) return rc; }

@@ -1,5 +1,6 @@
 // lds_inst.hip -- one (field, LOGN) instance of the LDS-resident kernels.
 // Compile with -DFHE_FIELD=F32|F52|F64|F64X -DFHE_LOGN=11..15 (the Makefile lists the instances).
+#include <cstdlib>
 #include "lds_launch.h"
 #include "ntt_lds.hip.h"
 #include "ntt_lds_small.hip.h"
@@ -21,6 +22,20 @@ static bool launch_small_multiply(const LdsArgs &A, const Limb<F> *limbs) {
     }
 }
 
+// a handful of polynomials: each one over four workgroups, three dependent launches (ntt_lds_small.hip.h)
+template <class F, int LOGN>
+static bool launch_coop4_multiply(const LdsArgs &A, const Limb<F> *limbs) {
+    using E = typename F::E;
+    if constexpr (lds_coop4_multiply(sizeof(E), LOGN)) {
+        const dim3 grid(A.polys * 4), block(Coop4<F, LOGN>::T);
+        hipLaunchKernelGGL((ntt_multiply4_top_kernel<F, LOGN>), grid, block, 0, A.stream, (const char *)A.a0, (const char *)A.b0, (E *)A.coop_ws, limbs, A.L, A.b_polys ? 1u : 0u);
+        hipLaunchKernelGGL((ntt_multiply4_block_kernel<F, LOGN>), grid, block, 0, A.stream, (E *)A.coop_ws, limbs, A.L);
+        hipLaunchKernelGGL((ntt_multiply4_last_kernel<F, LOGN>), grid, block, 0, A.stream, (char *)A.r0, (const E *)A.coop_ws, limbs, A.L);
+        return true;
+    } else {
+        return false;
+    }
+}
 // tensor product with compact outputs for few ciphertexts (the first half of the one-call multiply + relinearise)
 template <class F, int LOGN>
 static bool launch_small_ct_multiply(const LdsArgs &A, const Limb<F> *limbs) {
@@ -99,6 +114,7 @@ void CAT(lds_launch_, FHE_FIELD, FHE_LOGN)(const LdsArgs &A) {
             hipLaunchKernelGGL((ntt_inverse_kernel<F, LOGN>), grid, block, 0, A.stream, (char *)A.r0, limbs, A.L);
             break;
         case LDS_MULTIPLY:
+            if (A.coop_ws && launch_coop4_multiply<F, LOGN>(A, limbs)) break;     // a handful of polynomials: four workgroups each
             if (A.small_batch && launch_small_multiply<F, LOGN>(A, limbs)) break;   // few polynomials: one workgroup's latency is what counts (ntt_lds_small.hip.h)
             if (A.square)
                 hipLaunchKernelGGL((ntt_multiply_kernel<F, LOGN, MULT_MINW, true>), grid, block, 0, A.stream, (char *)A.r0, (const char *)A.a0,

@@ -49,6 +49,8 @@ constexpr bool lds_compact_c2(int elem_bytes, int log_n) { return lds_keyswitch_
 // latency kernel of ntt_lds_small.hip.h; 4-byte residues only (its 90 preloaded 4-byte twiddles fit the register file, 8-byte ones do not)
 // (N = 2^14 would be 1024 threads under the 128-VGPR cap: the preloaded twiddles spill 51-163 VGPRs there, so that size keeps the 32-per-thread kernels)
 constexpr bool lds_small_multiply(int elem_bytes, int log_n) { return elem_bytes == 4 && log_n <= 13; }
+// ... and for a handful of polynomials one polynomial over four workgroups (ntt_multiply_coop4_kernel)
+constexpr bool lds_coop4_multiply(int elem_bytes, int log_n) { return elem_bytes == 4 && (log_n == 13 || log_n == 14); }
 
 struct LdsArgs {
     int op;
@@ -77,6 +79,8 @@ struct LdsArgs {
     bool rconst = false;                 // LDS_PASS_INV: scale with the constants that also absorb the 2^-W of a fused pointwise product
     // (new members go at the END: objects of the other instances stay layout-compatible during development, scripts/dev_relink.sh)
     bool small_batch = false;            // LDS_MULTIPLY: use the latency kernel where lds_small_multiply holds (never with compact_c2)
+    void *coop_ws = nullptr;             // LDS_MULTIPLY, N = 2^13 / 2^14, 4-byte residues, a handful of polynomials: 3 * polys * n residues -- four workgroups per
+                                         // polynomial in three dependent launches (ntt_multiply4_*_kernel)
     void *pair_ws = nullptr;             // LDS_KEYSWITCH, paired kernel, few ciphertexts: 2 * polys * ceil(L K / 2) * n residues -- one workgroup per digit PAIR
                                          // (ntt_keyswitch2_part_kernel) and a combining launch instead of one workgroup per (ciphertext, limb)
 };

@@ -63,12 +63,12 @@ __device__ __forceinline__ void get16(const E *lds, uint32_t tid, E (&x)[16]) {
 
 // the 2^(KHI+1) - 2^KLO per-lane twiddles of the stages on r-bits KLO..KHI of pattern Pat; stage k, twiddle j = r >> (k+1): slot (8 >> k) - 1 + j
 template <class F, int LOGN, class Pat, int KHI, int KLO>
-__device__ __forceinline__ void preload16(typename F::TW (&w)[15], uint32_t tid, const typename F::TW *__restrict__ tw) {
+__device__ __forceinline__ void preload16(typename F::TW (&w)[15], uint32_t tid, const typename F::TW *__restrict__ tw, uint32_t pre = 1) {
     const uint32_t base = Pat::base(tid);
 #pragma unroll
     for (int k = KLO; k <= KHI; k++) {
         const int b = Pat::BIT0 + k;
-        const typename F::TW *p = tw + ((1u << (LOGN - 1 - b)) + (base >> (b + 1)));
+        const typename F::TW *p = tw + ((pre << (LOGN - 1 - b)) + (base >> (b + 1)));     // pre != 1: block pre - 2^k of a larger transform (see fwd_stages, SUB)
 #pragma unroll
         for (int j = 0; j < (8 >> k); j++) w[(8 >> k) - 1 + j] = load_global(p + j);
     }
@@ -77,12 +77,12 @@ __device__ __forceinline__ void preload16(typename F::TW (&w)[15], uint32_t tid,
 // kernel like the others -- left where they are used, the first transform waited for four dependent scalar-cache misses (~9 K cycles,
 // scripts/small_batch_timeline.py)
 template <class F, int LOGN, int KHI, int KLO>
-__device__ __forceinline__ void preload16_uniform(typename F::TW (&w)[15], const typename F::TW *__restrict__ tw) {
+__device__ __forceinline__ void preload16_uniform(typename F::TW (&w)[15], const typename F::TW *__restrict__ tw, uint32_t pre = 1) {
     using Pat = P16A<LOGN>;
 #pragma unroll
     for (int k = KLO; k <= KHI; k++) {
         const int b = Pat::BIT0 + k;
-        const typename F::TW *p = tw + (1u << (LOGN - 1 - b));
+        const typename F::TW *p = tw + (pre << (LOGN - 1 - b));
 #pragma unroll
         for (int j = 0; j < (8 >> k); j++) w[(8 >> k) - 1 + j] = load_global(p + j);
     }
@@ -149,15 +149,19 @@ template <class F, int LOGN>
 struct Twiddles16 {
     using C = Cfg16<LOGN>;
     typename F::TW fa[15], f1[15], f2[15], fz[15], iz[15], i1[15], i2[15], ia[15];     // fa / ia: the uniform pattern-A groups (SGPRs)
-    __device__ __forceinline__ void load(uint32_t tid, const Limb<F> &P) {
-        preload16_uniform<F, LOGN, 3, 0>(fa, P.tw);
-        if constexpr (C::REM > 1) preload16_uniform<F, LOGN, 2, 4 - C::REM>(ia, P.itw);
-        preload16<F, LOGN, P16Mid<LOGN, LOGN - 8>, 3, 0>(f1, tid, P.tw);
-        if constexpr (C::NG == 4) preload16<F, LOGN, P16Mid<LOGN, LOGN - 12>, 3, 0>(f2, tid, P.tw);
-        preload16<F, LOGN, P16Z<LOGN>, C::REM - 1, 0>(fz, tid, P.tw);
-        preload16<F, LOGN, P16Z<LOGN>, 3, 0>(iz, tid, P.itw);
-        preload16<F, LOGN, P16Mid<LOGN, 4>, 3, 0>(i1, tid, P.itw);
-        if constexpr (C::NG == 4) preload16<F, LOGN, P16Mid<LOGN, 8>, 3, 0>(i2, tid, P.itw);
+    // SUB: the 2^LOGN coefficients are block pre - 2^k of a transform of 2^(LOGN + k) coefficients (twiddles from the big table; the last inverse group
+    // is made of ordinary stages, the scaling belongs to the pass over the top stages)
+    template <bool SUB = false>
+    __device__ __forceinline__ void load(uint32_t tid, const Limb<F> &P, uint32_t pre = 1) {
+        preload16_uniform<F, LOGN, 3, 0>(fa, P.tw, pre);
+        if constexpr (SUB) preload16_uniform<F, LOGN, 3, 4 - C::REM>(ia, P.itw, pre);
+        else if constexpr (C::REM > 1) preload16_uniform<F, LOGN, 2, 4 - C::REM>(ia, P.itw);
+        preload16<F, LOGN, P16Mid<LOGN, LOGN - 8>, 3, 0>(f1, tid, P.tw, pre);
+        if constexpr (C::NG == 4) preload16<F, LOGN, P16Mid<LOGN, LOGN - 12>, 3, 0>(f2, tid, P.tw, pre);
+        preload16<F, LOGN, P16Z<LOGN>, C::REM - 1, 0>(fz, tid, P.tw, pre);
+        preload16<F, LOGN, P16Z<LOGN>, 3, 0>(iz, tid, P.itw, pre);
+        preload16<F, LOGN, P16Mid<LOGN, 4>, 3, 0>(i1, tid, P.itw, pre);
+        if constexpr (C::NG == 4) preload16<F, LOGN, P16Mid<LOGN, 8>, 3, 0>(i2, tid, P.itw, pre);
     }
 };
 
@@ -184,7 +188,7 @@ __device__ __forceinline__ void fwd_core16(typename F::E (&x)[16], typename F::E
     fwd16_pre<F, C::REM - 1, 0>(x, W.fz, P);
 }
 // NTT values in pattern Z -> coefficients in pattern A, scaled by the (ninv..) constants
-template <class F, int LOGN>
+template <class F, int LOGN, bool SUB = false>
 __device__ __forceinline__ void inv_core16(typename F::E (&x)[16], typename F::E *lds, uint32_t tid, const Limb<F> &P, const Twiddles16<F, LOGN> &W,
                                            typename F::E ninv, typename F::E ninv_s, typename F::E ninvw, typename F::E ninvw_s) {
     using C = Cfg16<LOGN>;
@@ -208,9 +212,14 @@ __device__ __forceinline__ void inv_core16(typename F::E (&x)[16], typename F::E
     }
     get16<P16A<LOGN>>(lds, tid, x);
     // index bits [4*(NG-1), LOGN-1) <-> r-bits [4-REM, 3) ; bit LOGN-1 <-> r-bit 3 is the scaled last stage
-    if constexpr (C::REM > 1) inv16_pre<F, 4 - C::REM, 2>(x, W.ia, P);
+    if constexpr (SUB) {        // a block of a larger transform: every stage of the group is an ordinary one
+        inv16_pre<F, 4 - C::REM, 3>(x, W.ia, P);
+        regroup16<F>(x, P.q, P.qinv);
+    } else {
+        if constexpr (C::REM > 1) inv16_pre<F, 4 - C::REM, 2>(x, W.ia, P);
 #pragma unroll
-    for (int r = 0; r < 8; r++) F::inv_last(x[r], x[r | 8], P.q, P.q2, ninv, ninv_s, ninvw, ninvw_s);
+        for (int r = 0; r < 8; r++) F::inv_last(x[r], x[r | 8], P.q, P.q2, ninv, ninv_s, ninvw, ninvw_s);
+    }
 }
 
 template <class F, int LOGN>
@@ -257,7 +266,7 @@ ntt16_multiply_kernel(char *res, const char *a, const char *b, const Limb<F> *__
     // which the issuing waves are blocked on the full address FIFO) would otherwise delay them by the same ~9 K cycles (timeline of
     // scripts/small_batch_timeline.py: first forward transform 18.5 K cycles against 9.1 K for the second)
     Twiddles16<F, LOGN> W;
-    W.load(tid, P);
+    W.template load<false>(tid, P);
     load16<F, LOGN>(a + off, tid, x);
     load16<F, LOGN>(b + (size_t)(bcast ? limb : p) * (C::N * 32), tid, y);
     STAMP(1);
@@ -287,6 +296,117 @@ ntt16_multiply_kernel(char *res, const char *a, const char *b, const Limb<F> *__
     STAMP(6);
 }
 
+// ---- ONE polynomial over FOUR workgroups: the fused product for the smallest batches -----------------------------------------------------
+// The timeline of ntt16_multiply_kernel (scripts/small_batch_timeline.py) shows what bounds a lone workgroup: one CU needs ~19 K cycles to ingest
+// the 512 KiB of container lines of an operand pair and ~4.5 K to emit the result -- 10 of its 22 us are the container format moving through a
+// single CU.  Here every (polynomial, limb) is shared by Q = 4 workgroups (4 CUs) in three phases, each its own launch (the stream order is the
+// barrier between them; what crosses is a compact polynomial in a library workspace):
+//   1. workgroup k loads a quarter of the COLUMNS of a and b (column c = coefficients c, c + N/4, c + N/2, c + 3N/4), runs the top two forward
+//      stages on them in registers (radix 4, wave-uniform twiddles tw[1..3]) and writes the four results of each column to the workspace;
+//   2. workgroup q runs block q (N/4 consecutive coefficients) of both operands: 16-per-thread sub-transforms with the big transform's twiddles
+//      (SUB, pre = 4 + q), pointwise product, inverse sub-transform, compact result;
+//   3. workgroup k runs the last two inverse stages on its columns (n^-1 folded into the final butterfly) and stores its quarter of the containers.
+// Each CU ingests a quarter of the lines.  (The same three phases as ONE kernel with atomic-counter barriers between the four workgroups of a
+// polynomial were measured first: 16.5 us of kernel time either way, but hipLaunchCooperativeKernel -- the only launch that guarantees the
+// co-residency such barriers need -- costs ~20 us per call on this stack, and an ordinary launch of spinning workgroups is not something a
+// library should do.  Three dependent launches need no guarantee and can be captured into a graph.)
+template <class F, int LOGN>
+struct Coop4 {
+    static_assert(LOGN == 13 || LOGN == 14, "four workgroups per polynomial: N = 2^13, 2^14");
+    static constexpr int LOGS = LOGN - 2;                 // log2 of a block
+    using S = Cfg16<LOGS>;
+    static constexpr int T = S::T;                        // threads per workgroup (128 / 256)
+    static constexpr int NS = 1 << LOGS;                  // coefficients per block = columns of the top stages
+    static constexpr int CPT = NS / 4 / T;                // columns per thread in phases 1 and 3 (= 4)
+};
+// ws: per polynomial three compact polynomials (top(a), top(b), block results)
+template <class F, int LOGN>
+__global__ void __launch_bounds__(1 << (LOGN - 6))      // = Coop4<F, LOGN>::T (a comma inside the macro argument would split it)
+ntt_multiply4_top_kernel(const char *a, const char *b, typename F::E *ws, const Limb<F> *__restrict__ limbs, uint32_t L, uint32_t bcast) {
+    using K = Coop4<F, LOGN>;
+    using E = typename F::E;
+    constexpr int NS = K::NS, T = K::T, N = 1 << LOGN;
+    const uint32_t tid = threadIdx.x, p = blockIdx.x >> 2, k = blockIdx.x & 3, limb = p % L;
+    const Limb<F> P = limbs[limb];
+    E *wa = ws + (size_t)p * (3 * N), *wb = wa + N;
+    const typename F::TW t1 = load_global(P.tw + 1), t2 = load_global(P.tw + 2), t3 = load_global(P.tw + 3);
+    const char *pa = a + (size_t)p * (N * 32), *pb = b + (size_t)(bcast ? limb : p) * (N * 32);
+    E xa[K::CPT][4], xb[K::CPT][4];
+#pragma unroll
+    for (int m = 0; m < K::CPT; m++) {
+        const uint32_t c = k * (NS / 4) + tid + m * T;
+#pragma unroll
+        for (int q = 0; q < 4; q++) { xa[m][q] = F::load_low(pa + (size_t)(q * NS + c) * 32); xb[m][q] = F::load_low(pb + (size_t)(q * NS + c) * 32); }
+    }
+#pragma unroll
+    for (int m = 0; m < K::CPT; m++) {
+        const uint32_t c = k * (NS / 4) + tid + m * T;
+        F::fwd_bfly(xa[m][0], xa[m][2], t1, P); F::fwd_bfly(xa[m][1], xa[m][3], t1, P);      // index bit LOGN-1
+        F::fwd_bfly(xa[m][0], xa[m][1], t2, P); F::fwd_bfly(xa[m][2], xa[m][3], t3, P);      // index bit LOGN-2
+        F::fwd_bfly(xb[m][0], xb[m][2], t1, P); F::fwd_bfly(xb[m][1], xb[m][3], t1, P);
+        F::fwd_bfly(xb[m][0], xb[m][1], t2, P); F::fwd_bfly(xb[m][2], xb[m][3], t3, P);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            wa[q * NS + c] = F::canon_fwd(xa[m][q], P.q, P.q2, P.qinv);
+            wb[q * NS + c] = F::canon_fwd(xb[m][q], P.q, P.q2, P.qinv);
+        }
+    }
+}
+template <class F, int LOGN>
+__global__ void __launch_bounds__(1 << (LOGN - 6))
+ntt_multiply4_block_kernel(typename F::E *ws, const Limb<F> *__restrict__ limbs, uint32_t L) {
+    using K = Coop4<F, LOGN>;
+    using E = typename F::E;
+    constexpr int LOGS = K::LOGS, NS = K::NS, T = K::T, N = 1 << LOGN;
+    __shared__ E lds[NS];
+    const uint32_t tid = threadIdx.x, p = blockIdx.x >> 2, k = blockIdx.x & 3;
+    const Limb<F> P = limbs[p % L];
+    E *wa = ws + (size_t)p * (3 * N), *wb = wa + N, *wr = wb + N;
+    Twiddles16<F, LOGS> W;
+    W.template load<true>(tid, P, 4 + k);
+    E x[16], y[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) { x[r] = wa[k * NS + tid + r * T]; y[r] = wb[k * NS + tid + r * T]; }
+    fwd_core16<F, LOGS>(x, lds, tid, P, W);
+#pragma unroll
+    for (int r = 0; r < 16; r++) x[r] = F::canon_fwd(x[r], P.q, P.q2, P.qinv);
+    __syncthreads();
+    fwd_core16<F, LOGS>(y, lds, tid, P, W);
+#pragma unroll
+    for (int r = 0; r < 16; r++) x[r] = F::pw_mul(x[r], y[r], P.q, P.qinv);               // carries 2^-W until the last stage (ninv_r constants)
+    inv_core16<F, LOGS, true>(x, lds, tid, P, W, P.ninv, P.ninv_s, P.ninvw, P.ninvw_s);
+#pragma unroll
+    for (int r = 0; r < 16; r++) wr[k * NS + tid + r * T] = F::canon_inv(x[r], P.q);
+}
+template <class F, int LOGN>
+__global__ void __launch_bounds__(1 << (LOGN - 6))
+ntt_multiply4_last_kernel(char *res, const typename F::E *ws, const Limb<F> *__restrict__ limbs, uint32_t L) {
+    using K = Coop4<F, LOGN>;
+    using E = typename F::E;
+    constexpr int NS = K::NS, T = K::T, N = 1 << LOGN;
+    const uint32_t tid = threadIdx.x, p = blockIdx.x >> 2, k = blockIdx.x & 3;
+    const Limb<F> P = limbs[p % L];
+    const E *wr = ws + (size_t)p * (3 * N) + 2 * N;
+    const typename F::TW i2 = load_global(P.itw + 2), i3 = load_global(P.itw + 3);
+    typename F::V16 *out = reinterpret_cast<typename F::V16 *>(res + (size_t)p * (N * 32));
+#pragma unroll
+    for (int m = 0; m < K::CPT; m++) {
+        const uint32_t c = k * (NS / 4) + tid + m * T;
+        E v[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) v[q] = wr[q * NS + c];
+        F::inv_bfly(v[0], v[1], i2, P); F::inv_bfly(v[2], v[3], i3, P);                     // index bit LOGN-2
+        F::inv_last(v[0], v[2], P.q, P.q2, P.ninv_r, P.ninv_r_s, P.ninvw_r, P.ninvw_r_s);   // index bit LOGN-1, scaled
+        F::inv_last(v[1], v[3], P.q, P.q2, P.ninv_r, P.ninv_r_s, P.ninvw_r, P.ninvw_r_s);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            typename F::V16 *d = out + 2 * (size_t)(q * NS + c);
+            __builtin_nontemporal_store(F::pack(F::canon_inv(F::regroup1(v[q], P.q, P.qinv), P.q)), d);
+            __builtin_nontemporal_store(F::pack((E)0), d + 1);
+        }
+    }
+}
+
 // Tensor product of FHEContext::multiply (src/fhe.cu:199-218) for few ciphertexts, outputs as COMPACT polynomials (the first half of the
 // one-call multiply + relinearise): c0 = a0 b0, c1 = a0 b1 + a1 b0, c2 = a1 b1.  Same latency argument as ntt16_multiply_kernel: twice the waves of
 // the 32-per-thread kernel on the same polynomial, every twiddle loaded once at the top beside the four operands.
@@ -303,7 +423,7 @@ ntt16_ct_multiply_kernel(typename F::E *__restrict__ c0, typename F::E *__restri
     const size_t off = (size_t)p * (C::N * 32), offc = (size_t)p * C::N;
     E A0[16], A1[16], B0[16], B1[16];
     Twiddles16<F, LOGN> W;
-    W.load(tid, P);
+    W.template load<false>(tid, P);
     load16<F, LOGN>(a0 + off, tid, A0);
     load16<F, LOGN>(a1 + off, tid, A1);
     load16<F, LOGN>(b0 + off, tid, B0);

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Small-batch latency of the fused polymul (configs[2]'s batch-1 shape): per-call time at batch 1 .. 256 with the latency kernel
-(default below 128 limb polynomials) and with the throughput kernel forced (FHE_HIP_SMALL_BATCH_POLYS=0), plus the launch floor.
+"""Small-batch latency of the fused polymul (configs[2]'s batch-1 shape): per-call time at batch 1 .. 256 with each polynomial over four workgroups
+(default up to 64 limb polynomials), the 16-per-thread latency kernel (default up to 256) and the throughput kernel, each forced, and the library's default choice.
 Writes one JSON line per (batch, kernel) to gpurun_out/small_batch_<tag>.jsonl.   usage: bench_small_batch2.py [tag] [batches, comma separated]"""
 import importlib, json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -11,11 +11,14 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 n, L = 8192, 4
 moduli = pkg.find_ntt_primes(30, n, L)
 out = open(os.path.join(ROOT, "gpurun_out", f"small_batch_{tag}.jsonl"), "w")
-def engine(polys):
-    if polys is not None: os.environ["FHE_HIP_SMALL_BATCH_POLYS"] = str(polys)
+def engine(small, coop):
+    """small / coop: FHE_HIP_SMALL_BATCH_POLYS / FHE_HIP_COOP_POLYS for this engine (None = the library's defaults)"""
+    for k, v in (("FHE_HIP_SMALL_BATCH_POLYS", small), ("FHE_HIP_COOP_POLYS", coop)):
+        if v is not None: os.environ[k] = str(v)
     try: return pkg.RnsNttEngine(n, moduli)
-    finally: os.environ.pop("FHE_HIP_SMALL_BATCH_POLYS", None)
-engs = {"latency-kernel": engine(1000000), "throughput-kernel": engine(0), "default": engine(None)}
+    finally:
+        os.environ.pop("FHE_HIP_SMALL_BATCH_POLYS", None); os.environ.pop("FHE_HIP_COOP_POLYS", None)
+engs = {"four-workgroups-three-launches": engine(None, 1000000), "latency-kernel": engine(1000000, 0), "throughput-kernel": engine(0, 0), "default": engine(None, None)}
 BATCHES = [int(v) for v in sys.argv[2].split(',')] if len(sys.argv) > 2 else [1, 2, 4, 8, 16, 32, 64, 128, 256]
 for B in BATCHES:
     a = pkg.DeviceBuffer.from_numpy(rns_poly(1, moduli, n, B)); b = pkg.DeviceBuffer.from_numpy(rns_poly(2, moduli, n, B)); r = pkg.DeviceBuffer(B * L * n * 32)

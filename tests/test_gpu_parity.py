@@ -149,10 +149,11 @@ def test_forward_inverse_multiply_match_oracle(eng, oracle, monkeypatch, n, spec
     if width == eng.WIDTH_32 and n <= 8192:
         # few polynomials run the 16-per-thread latency kernel (ntt_lds_small.hip.h) by default: the throughput kernel on the same operands,
         # and the latency kernel forced for any batch, must give the same containers
-        for polys in ("0", "1000000"):
+        for polys in ("0", "1000000"):           # (the default engine above spread each polynomial over four workgroups at N = 8192: ntt_multiply4_*_kernel)
             monkeypatch.setenv("FHE_HIP_SMALL_BATCH_POLYS", polys)
+            monkeypatch.setenv("FHE_HIP_COOP_POLYS", "0")
             e2 = eng.RnsNttEngine(n, moduli)
-            monkeypatch.delenv("FHE_HIP_SMALL_BATCH_POLYS")
+            monkeypatch.delenv("FHE_HIP_SMALL_BATCH_POLYS"); monkeypatch.delenv("FHE_HIP_COOP_POLYS")
             dR.zero(); e2.multiply(dR, dA, dB, batch)
             assert np.array_equal(dR.download(shape), want_mul), polys
             dC = _up(eng, a); e2.multiply(dC, dC, dB, batch)                    # in place on the first operand
@@ -167,6 +168,35 @@ def test_forward_inverse_multiply_match_oracle(eng, oracle, monkeypatch, n, spec
                                for l in range(L)]) for bi in range(batch)])
     assert np.array_equal(dR.download(shape), want)
     e.check_canonical(dR, batch)
+
+
+@pytest.mark.parametrize("n,L,batch", [(8192, 4, 1), (8192, 4, 4), (8192, 1, 3), (16384, 6, 2), (16384, 3, 1), (8192, 2, 8)])
+def test_multiply_one_polynomial_over_four_workgroups(eng, oracle, monkeypatch, n, L, batch):
+    """ntt_multiply4_{top,block,last}_kernel (a handful of polynomials at N = 2^13 / 2^14 on 4-byte residues): each polynomial over four workgroups in three
+    dependent launches (top two stages by columns, 16-per-thread sub-transforms + pointwise product on the four blocks, last two inverse stages by columns).
+    Repeated calls, in-place products, a broadcast operand, and the same product from the one-workgroup kernels (FHE_HIP_COOP_POLYS=0); all equal to the oracle."""
+    moduli = _moduli(("bits", 30, L), n)
+    e = eng.RnsNttEngine(n, moduli); rp = oracle.RnsPlan(n, moduli)
+    monkeypatch.setenv("FHE_HIP_COOP_POLYS", "0")
+    e0 = eng.RnsNttEngine(n, moduli)
+    monkeypatch.delenv("FHE_HIP_COOP_POLYS")
+    for rep in range(3):
+        a = rns_poly(70 + rep, moduli, n, batch); b = rns_poly(80 + rep, moduli, n, batch)
+        dA, dB, dR = _up(eng, a), _up(eng, b), eng.DeviceBuffer(a.nbytes)
+        want = rp.polymul(a, b, threads=8)
+        for _ in range(4):                                        # back-to-back launches on one stream
+            e.multiply(dR, dA, dB, batch)
+        assert np.array_equal(dR.download(a.shape), want), rep
+        assert np.array_equal(dA.download(a.shape), a) and np.array_equal(dB.download(a.shape), b)
+        dR.zero(); e0.multiply(dR, dA, dB, batch)
+        assert np.array_equal(dR.download(a.shape), want)
+        dC = _up(eng, a); e.multiply(dC, dC, dB, batch)           # in place on the first operand
+        assert np.array_equal(dC.download(a.shape), want)
+        dC = _up(eng, a); e.multiply(dC, dC, dC, batch)           # in-place squaring
+        assert np.array_equal(dC.download(a.shape), rp.polymul(a, a, threads=8))
+    one = rns_poly(99, moduli, n, 1)
+    dOne = _up(eng, one); e.multiply_bcast(dR, dA, dOne, batch)
+    assert np.array_equal(dR.download(a.shape), rp.polymul(a, np.repeat(one, batch, axis=0), threads=8))
 
 
 @pytest.mark.parametrize("n,spec,batch", [(2048, [40961], 2), (8192, ("bits", 30, 4), 2), (4096, ("bits", 60, 2), 1),
