@@ -248,7 +248,7 @@ struct fhe_rns_ntt {
     hipEvent_t ev_chunk[16] = {}, ev_join = nullptr;   // tensor product of chunk i done (engine stream) -> key switch of chunk i may start (second stream)
     uint32_t small_batch_polys = 256;   // FHE_HIP_SMALL_BATCH_POLYS: fused multiply of at most this many limb polynomials runs the 16-per-thread latency kernel (0 = never)
     uint32_t coop_polys = 64;           // FHE_HIP_COOP_POLYS: fused multiply of at most this many limb polynomials (N = 2^13 / 2^14, 4-byte residues) spreads each over four workgroups in three launches (0 = never)
-    uint32_t split_pairs_polys = 64;    // FHE_HIP_SPLIT_PAIRS_POLYS: key switch (paired kernel) of at most this many limb polynomials runs one workgroup per digit pair + a combining launch (0 = never)
+    uint32_t split_pairs_polys = 128;   // FHE_HIP_SPLIT_PAIRS_POLYS: key switch (paired kernel) of at most this many limb polynomials runs one workgroup per digit pair + a combining launch (0 = never)
     bool relin_chunks_forced = false;   // FHE_HIP_RELIN_PIPELINE=1: the stand-alone relinearisation also runs as a two-stream pipeline (A/B)
     uint32_t overlap_chunks = 4;        // FHE_HIP_CT_RELIN_CHUNKS: pieces the one-call multiply is cut into (1 = one stream, as in round 2)
     void *d_limbs = nullptr;            // owned by d_tables
@@ -1329,6 +1329,10 @@ extern "C" int fhe_ct_multiply_relin(fhe_rns_ntt_t *h, const fhe_relin_keys_t *r
             A.compact_c2 = true;
             if (bws) A.ws = bws + 2 * oc;                        // two compact polynomials per limb polynomial of the chunk
             A.small_batch = A.polys <= h->split_pairs_polys;     // few ciphertexts: the 16-per-thread tensor product (and, below, the split key switch)
+            if (chunks == 1 && !bws && A.polys <= h->coop_polys && h->width == FHE_WIDTH_32 && fhe_dev::lds_coop4_multiply(4, (int)h->log_n)) {
+                if ((rc = ensure_ws3(h, 7 * (size_t)A.polys * h->n * 4))) return rc;      // a handful: four workgroups per limb polynomial, three launches
+                A.coop_ws = h->d_ws3;
+            }
             fn(A);
             if ((rc = post_launch(h->stream, "tensor product (compact outputs)"))) return rc;
             hipStream_t ks = h->stream;

@@ -36,6 +36,21 @@ static bool launch_coop4_multiply(const LdsArgs &A, const Limb<F> *limbs) {
         return false;
     }
 }
+// tensor product with compact outputs of a handful of ciphertexts: four workgroups per (ciphertext, limb), three launches
+template <class F, int LOGN>
+static bool launch_coop4_ct_multiply(const LdsArgs &A, const Limb<F> *limbs) {
+    using E = typename F::E;
+    if constexpr (lds_coop4_multiply(sizeof(E), LOGN)) {
+        const dim3 block(Coop4<F, LOGN>::T);
+        hipLaunchKernelGGL((ntt_ct4_top_kernel<F, LOGN>), dim3(A.polys * 4, 4), block, 0, A.stream, (const char *)A.a0, (const char *)A.a1, (const char *)A.b0,
+                           (const char *)A.b1, (E *)A.coop_ws, limbs, A.L);
+        hipLaunchKernelGGL((ntt_ct4_block_kernel<F, LOGN>), dim3(A.polys * 4), block, 0, A.stream, (E *)A.coop_ws, limbs, A.L);
+        hipLaunchKernelGGL((ntt_ct4_last_kernel<F, LOGN>), dim3(A.polys * 4, 3), block, 0, A.stream, (E *)A.r0, (E *)A.r1, (E *)A.r2, (const E *)A.coop_ws, limbs, A.L);
+        return true;
+    } else {
+        return false;
+    }
+}
 // tensor product with compact outputs for few ciphertexts (the first half of the one-call multiply + relinearise)
 template <class F, int LOGN>
 static bool launch_small_ct_multiply(const LdsArgs &A, const Limb<F> *limbs) {
@@ -124,6 +139,7 @@ void CAT(lds_launch_, FHE_FIELD, FHE_LOGN)(const LdsArgs &A) {
                                    (const char *)A.b0, limbs, A.L, A.b_polys ? 1u : 0u);
             break;
         case LDS_CT_MULTIPLY:
+            if (A.coop_ws && A.compact_c2 && !A.ws && launch_coop4_ct_multiply<F, LOGN>(A, limbs)) break;   // a handful of ciphertexts: four workgroups per limb polynomial
             if (A.small_batch && A.compact_c2 && !A.ws && launch_small_ct_multiply<F, LOGN>(A, limbs)) break;   // few ciphertexts (ntt_lds_small.hip.h)
             if (A.ws) {                  // two launches: the b-side transforms into the workspace, then one workgroup per (ciphertext, limb) does the rest
                 if constexpr (lds_ct_two_launch(sizeof(typename F::E), LOGN)) {

@@ -407,6 +407,107 @@ ntt_multiply4_last_kernel(char *res, const typename F::E *ws, const Limb<F> *__r
     }
 }
 
+// ---- the tensor product of few ciphertexts the same way: four workgroups per (ciphertext, limb), three launches, COMPACT outputs -------------
+// (the first half of the one-call multiply + relinearise; ws: per limb polynomial 4 operand + 3 result compact polynomials)
+template <class F, int LOGN>
+__global__ void __launch_bounds__(1 << (LOGN - 6))
+ntt_ct4_top_kernel(const char *a0, const char *a1, const char *b0, const char *b1, typename F::E *ws, const Limb<F> *__restrict__ limbs, uint32_t L) {
+    using K = Coop4<F, LOGN>;
+    using E = typename F::E;
+    constexpr int NS = K::NS, T = K::T, N = 1 << LOGN;
+    const uint32_t tid = threadIdx.x, p = blockIdx.x >> 2, k = blockIdx.x & 3;
+    const uint32_t which = blockIdx.y;                    // operand 0..3 (grid.y = 4): 16 workgroups per (ciphertext, limb) in this phase
+    const Limb<F> P = limbs[p % L];
+    const char *src = (which == 0 ? a0 : which == 1 ? a1 : which == 2 ? b0 : b1) + (size_t)p * (N * 32);
+    E *w = ws + (size_t)p * (7 * N) + (size_t)which * N;
+    const typename F::TW t1 = load_global(P.tw + 1), t2 = load_global(P.tw + 2), t3 = load_global(P.tw + 3);
+    E x[K::CPT][4];
+#pragma unroll
+    for (int m = 0; m < K::CPT; m++) {
+        const uint32_t c = k * (NS / 4) + tid + m * T;
+#pragma unroll
+        for (int q = 0; q < 4; q++) x[m][q] = F::load_low(src + (size_t)(q * NS + c) * 32);
+    }
+#pragma unroll
+    for (int m = 0; m < K::CPT; m++) {
+        const uint32_t c = k * (NS / 4) + tid + m * T;
+        F::fwd_bfly(x[m][0], x[m][2], t1, P); F::fwd_bfly(x[m][1], x[m][3], t1, P);
+        F::fwd_bfly(x[m][0], x[m][1], t2, P); F::fwd_bfly(x[m][2], x[m][3], t3, P);
+#pragma unroll
+        for (int q = 0; q < 4; q++) w[q * NS + c] = F::canon_fwd(x[m][q], P.q, P.q2, P.qinv);
+    }
+}
+template <class F, int LOGN>
+__global__ void __launch_bounds__(1 << (LOGN - 6))
+ntt_ct4_block_kernel(typename F::E *ws, const Limb<F> *__restrict__ limbs, uint32_t L) {
+    using K = Coop4<F, LOGN>;
+    using E = typename F::E;
+    constexpr int LOGS = K::LOGS, NS = K::NS, T = K::T, N = 1 << LOGN;
+    __shared__ E lds[NS];
+    const uint32_t tid = threadIdx.x, p = blockIdx.x >> 2, k = blockIdx.x & 3;
+    const Limb<F> P = limbs[p % L];
+    E *w = ws + (size_t)p * (7 * N);
+    Twiddles16<F, LOGS> W;
+    W.template load<true>(tid, P, 4 + k);
+    E A0[16], A1[16], B0[16], B1[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const uint32_t i = k * NS + tid + r * T;
+        A0[r] = w[i]; A1[r] = w[N + i]; B0[r] = w[2 * N + i]; B1[r] = w[3 * N + i];
+    }
+    fwd_core16<F, LOGS>(A0, lds, tid, P, W);
+    __syncthreads();
+    fwd_core16<F, LOGS>(A1, lds, tid, P, W);
+    __syncthreads();
+    fwd_core16<F, LOGS>(B0, lds, tid, P, W);
+    __syncthreads();
+    fwd_core16<F, LOGS>(B1, lds, tid, P, W);
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const E u0 = F::canon_fwd(A0[r], P.q, P.q2, P.qinv), u1 = F::canon_fwd(A1[r], P.q, P.q2, P.qinv);
+        const E v0 = B0[r], v1 = B1[r];
+        A0[r] = F::pw_mul(u0, v0, P.q, P.qinv);
+        A1[r] = F::pw_mul2(u0, v1, u1, v0, P.q, P.q2, P.qinv);
+        B0[r] = F::pw_mul(u1, v1, P.q, P.qinv);
+    }
+    inv_core16<F, LOGS, true>(A0, lds, tid, P, W, P.ninv, P.ninv_s, P.ninvw, P.ninvw_s);
+#pragma unroll
+    for (int r = 0; r < 16; r++) w[4 * N + k * NS + tid + r * T] = F::canon_inv(A0[r], P.q);
+    __syncthreads();
+    inv_core16<F, LOGS, true>(A1, lds, tid, P, W, P.ninv, P.ninv_s, P.ninvw, P.ninvw_s);
+#pragma unroll
+    for (int r = 0; r < 16; r++) w[5 * N + k * NS + tid + r * T] = F::canon_inv(A1[r], P.q);
+    __syncthreads();
+    inv_core16<F, LOGS, true>(B0, lds, tid, P, W, P.ninv, P.ninv_s, P.ninvw, P.ninvw_s);
+#pragma unroll
+    for (int r = 0; r < 16; r++) w[6 * N + k * NS + tid + r * T] = F::canon_inv(B0[r], P.q);
+}
+template <class F, int LOGN>
+__global__ void __launch_bounds__(1 << (LOGN - 6))
+ntt_ct4_last_kernel(typename F::E *__restrict__ c0, typename F::E *__restrict__ c1, typename F::E *__restrict__ c2, const typename F::E *ws,
+                    const Limb<F> *__restrict__ limbs, uint32_t L) {
+    using K = Coop4<F, LOGN>;
+    using E = typename F::E;
+    constexpr int NS = K::NS, T = K::T, N = 1 << LOGN;
+    const uint32_t tid = threadIdx.x, p = blockIdx.x >> 2, k = blockIdx.x & 3, which = blockIdx.y;     // grid.y = 3 outputs
+    const Limb<F> P = limbs[p % L];
+    const E *wr = ws + (size_t)p * (7 * N) + (size_t)(4 + which) * N;
+    E *out = (which == 0 ? c0 : which == 1 ? c1 : c2) + (size_t)p * N;
+    const typename F::TW i2 = load_global(P.itw + 2), i3 = load_global(P.itw + 3);
+#pragma unroll
+    for (int m = 0; m < K::CPT; m++) {
+        const uint32_t c = k * (NS / 4) + tid + m * T;
+        E v[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) v[q] = wr[q * NS + c];
+        F::inv_bfly(v[0], v[1], i2, P); F::inv_bfly(v[2], v[3], i3, P);
+        F::inv_last(v[0], v[2], P.q, P.q2, P.ninv_r, P.ninv_r_s, P.ninvw_r, P.ninvw_r_s);
+        F::inv_last(v[1], v[3], P.q, P.q2, P.ninv_r, P.ninv_r_s, P.ninvw_r, P.ninvw_r_s);
+#pragma unroll
+        for (int q = 0; q < 4; q++) out[q * NS + c] = F::canon_inv(F::regroup1(v[q], P.q, P.qinv), P.q);
+    }
+}
+
 // Tensor product of FHEContext::multiply (src/fhe.cu:199-218) for few ciphertexts, outputs as COMPACT polynomials (the first half of the
 // one-call multiply + relinearise): c0 = a0 b0, c1 = a0 b1 + a1 b0, c2 = a1 b1.  Same latency argument as ntt16_multiply_kernel: twice the waves of
 // the 32-per-thread kernel on the same polynomial, every twiddle loaded once at the top beside the four operands.

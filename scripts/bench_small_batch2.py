@@ -33,11 +33,12 @@ for B in BATCHES:
         out.write(json.dumps(line) + "\n"); print(line, flush=True)
 
 # full ciphertext multiply (configs[2]) at small batches: digit pairs of the key switch on separate workgroups (default below 256 limb polynomials) vs the one-launch kernel
-def engine2(split):
-    os.environ["FHE_HIP_SPLIT_PAIRS_POLYS"] = str(split)
+def engine2(split, coop):
+    os.environ["FHE_HIP_SPLIT_PAIRS_POLYS"] = str(split); os.environ["FHE_HIP_COOP_POLYS"] = str(coop)
     try: return pkg.RnsNttEngine(n, moduli)
-    finally: os.environ.pop("FHE_HIP_SPLIT_PAIRS_POLYS", None)
-engs2 = {"split-pairs": engine2(1000000), "one-launch": engine2(0)}
+    finally:
+        os.environ.pop("FHE_HIP_SPLIT_PAIRS_POLYS", None); os.environ.pop("FHE_HIP_COOP_POLYS", None)
+engs2 = {"four-workgroup-tensor-product+split-pairs": engine2(1000000, 64), "split-pairs": engine2(1000000, 0), "one-launch": engine2(0, 0), "default": pkg.RnsNttEngine(n, moduli)}
 w = 16
 for B in BATCHES:
     ops = [pkg.DeviceBuffer.from_numpy(rns_poly(10 + i, moduli, n, B)) for i in range(4)]

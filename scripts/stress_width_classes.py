@@ -32,9 +32,11 @@ while time.time() - t0 < budget:
     moduli = pkg.find_ntt_primes(bits, n, L)
     os.environ.pop("FHE_HIP_FORCE_WIDTH", None)
     fast = pkg.RnsNttEngine(n, moduli)
-    os.environ["FHE_HIP_SMALL_BATCH_POLYS"] = "0"      # the throughput multiply kernel for these small batches (the default engine takes the latency kernel)
-    fast_tp = pkg.RnsNttEngine(n, moduli)
-    os.environ.pop("FHE_HIP_SMALL_BATCH_POLYS", None)
+    os.environ["FHE_HIP_SMALL_BATCH_POLYS"] = "0"; os.environ["FHE_HIP_COOP_POLYS"] = "0"      # the throughput multiply kernel for these small batches
+    fast_tp = pkg.RnsNttEngine(n, moduli)                  # (the default engine takes the four-workgroup form or the latency kernel)
+    os.environ["FHE_HIP_SMALL_BATCH_POLYS"] = "1000000"
+    fast_lat = pkg.RnsNttEngine(n, moduli)                 # the 16-per-thread latency kernel forced
+    os.environ.pop("FHE_HIP_SMALL_BATCH_POLYS", None); os.environ.pop("FHE_HIP_COOP_POLYS", None)
     os.environ["FHE_HIP_FORCE_WIDTH"] = "256"
     wide = pkg.RnsNttEngine(n, moduli)
     os.environ["FHE_HIP_FORCE_WIDTH"] = "128"          # the same class on two 64-bit limbs (R = 2^128)
@@ -50,7 +52,7 @@ while time.time() - t0 < budget:
     info = dict(n=n, bits=bits, L=L, batch=batch, seed=seed)
     ref = {}
     for rep in range(3):
-        for eng, tag in ((wide, "wide"), (fast, "fast"), (fast_tp, "fast-throughput-kernel"), (wide2, "wide-2-limb"), (wide2p, "wide-2-limb-passes"), (fast, "fast"))[:6 if rep == 0 else 3]:
+        for eng, tag in ((wide, "wide"), (fast, "fast"), (fast_tp, "fast-throughput-kernel"), (fast_lat, "fast-latency-kernel"), (wide2, "wide-2-limb"), (wide2p, "wide-2-limb-passes"), (fast, "fast"))[:7 if rep == 0 else 4]:
             d = [pkg.DeviceBuffer.from_numpy(v) for v in x]
             o = [pkg.DeviceBuffer(x[0].nbytes) for _ in range(3)]
             eng.multiply(o[0], d[0], d[1], batch); launches += 1

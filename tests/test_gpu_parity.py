@@ -1342,14 +1342,18 @@ def test_check_inputs_switch_rejects_noncanonical_operands(eng, monkeypatch, bit
                                             (4096, ("bits", 40, 2), 20, 3), (8192, ("bits", 43, 2), 16, 1), (16384, ("bits", 40, 2), 20, 1),
                                             (2048, ("bits", 60, 2), 32, 2), (8192, ("bits", 64, 1), 32, 1), (256, ("bits", 250, 1), 64, 2),
                                             (2048, ("bits", 120, 1), 40, 1)])
-@pytest.mark.parametrize("fused", [True, False, "one-launch-keyswitch"])
+@pytest.mark.parametrize("fused", [True, False, "one-launch-keyswitch", "no-four-workgroups", "throughput-kernels"])
 def test_ct_multiply_relin_matches_oracle(eng, oracle, monkeypatch, n, spec, w, batch, fused):
     """FHEContext::multiply as the reference declares it (src/fhe.cu:199-224): tensor product + relinearisation in ONE call.  fused: c2
     crosses from the tensor-product kernel to the key-switch kernel in the compact workspace where both kernels exist (else, and with
     FHE_HIP_NO_FUSED_CT_RELIN=1, the two-call composition inside the library); every variant equals oracle ct_multiply + relinearize."""
-    if fused == "one-launch-keyswitch":   # few ciphertexts split the digit pairs of the paired key switch over workgroups by default: here the throughput form
+    # few ciphertexts (4-byte residues) take special forms by default: tensor product over four workgroups per limb polynomial in three launches (else the
+    # 16-per-thread kernel), key switch with one workgroup per digit pair + a combining launch; the variants switch them off one at a time and together
+    if fused in ("one-launch-keyswitch", "throughput-kernels"):
         monkeypatch.setenv("FHE_HIP_SPLIT_PAIRS_POLYS", "0")
-    elif not fused:
+    if fused in ("no-four-workgroups", "throughput-kernels"):
+        monkeypatch.setenv("FHE_HIP_COOP_POLYS", "0")
+    if fused is False:
         monkeypatch.setenv("FHE_HIP_NO_FUSED_CT_RELIN", "1")
     moduli = _moduli(spec, n); L = len(moduli)
     e = eng.RnsNttEngine(n, moduli); rp = oracle.RnsPlan(n, moduli)

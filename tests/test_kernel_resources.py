@@ -105,7 +105,8 @@ def test_small_batch_latency_kernel(resources):
     for name in ("ntt_keyswitch2_part_kernel", "ntt_keyswitch2_comb_kernel"):   # key switch of few ciphertexts: one workgroup per digit pair + combine
         for k in _all(kernels, name, 2):
             assert k["spill"] == 0 and k.get("scratch", 0) == 0 and k["vgprs"] <= 256 and k["occupancy"] >= 2 and k["lds"] == 2 * 33792, (name, k)
-    for name in ("ntt_multiply4_top_kernel", "ntt_multiply4_block_kernel", "ntt_multiply4_last_kernel"):   # one polynomial over four workgroups, three launches
+    for name in ("ntt_multiply4_top_kernel", "ntt_multiply4_block_kernel", "ntt_multiply4_last_kernel",     # one polynomial over four workgroups, three launches
+                 "ntt_ct4_top_kernel", "ntt_ct4_block_kernel", "ntt_ct4_last_kernel"):                     # ... and the tensor product of few ciphertexts the same way
         for k in _all(kernels, name, 1):
             assert k["spill"] == 0 and k.get("scratch", 0) == 0 and k["vgprs"] <= 256, (name, k)
     kernels14, _ = resources[("F32", 14)]                        # N = 2^14 would be 1024 threads at 128 VGPRs (the preloaded twiddles spill): not instantiated
