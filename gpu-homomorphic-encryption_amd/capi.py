@@ -67,6 +67,7 @@ def lib():
         "fhe_rns_ntt_set_stream": ([vp, vp], ci),
         "fhe_rns_ntt_width_class": ([vp], ci),
         "fhe_rns_ntt_reserve": ([vp, u32], ci),
+        "fhe_rns_ntt_workspace_bytes": ([vp, ctypes.POINTER(ctypes.c_uint64)], ci),
         "fhe_rns_ntt_forward": ([vp, vp, u32], ci),
         "fhe_rns_ntt_inverse": ([vp, vp, u32], ci),
         "fhe_rns_ntt_pointwise": ([vp, vp, vp, vp, u32], ci),
@@ -407,6 +408,12 @@ class RnsNttEngine:
     def reserve(self, batch):
         """Pre-size the library workspaces for calls of up to `batch` units (needed before hipGraph capture)."""
         _check(lib().fhe_rns_ntt_reserve(self.h, batch))
+
+    def workspace_bytes(self):
+        """Device bytes the engine's library-owned workspaces hold right now."""
+        out = ctypes.c_uint64(0)
+        _check(lib().fhe_rns_ntt_workspace_bytes(self.h, ctypes.byref(out)))
+        return out.value
 
     def ct_multiply_relin(self, rk, d_c0, d_c1, d_a0, d_a1, d_b0, d_b1, batch=1):
         """FHEContext::multiply: tensor product + relinearisation in one call (two components out)."""

@@ -248,6 +248,7 @@ struct fhe_rns_ntt {
     hipEvent_t ev_chunk[16] = {}, ev_join = nullptr;   // tensor product of chunk i done (engine stream) -> key switch of chunk i may start (second stream)
     uint32_t small_batch_polys = 256;   // FHE_HIP_SMALL_BATCH_POLYS: fused multiply of at most this many limb polynomials runs the 16-per-thread latency kernel (0 = never)
     uint32_t coop_polys = 64;           // FHE_HIP_COOP_POLYS: fused multiply of at most this many limb polynomials (N = 2^13 / 2^14, 4-byte residues) spreads each over four workgroups in three launches (0 = never)
+    uint32_t max_digits = 0, max_composed_digits = 0;   // largest digit count K of the key sets imported on this engine / of those without packed tables (fhe_rns_ntt_reserve)
     uint32_t split_pairs_polys = 128;   // FHE_HIP_SPLIT_PAIRS_POLYS: key switch (paired kernel) of at most this many limb polynomials runs one workgroup per digit pair + a combining launch (0 = never)
     bool relin_chunks_forced = false;   // FHE_HIP_RELIN_PIPELINE=1: the stand-alone relinearisation also runs as a two-stream pipeline (A/B)
     uint32_t overlap_chunks = 4;        // FHE_HIP_CT_RELIN_CHUNKS: pieces the one-call multiply is cut into (1 = one stream, as in round 2)
@@ -968,13 +969,36 @@ extern "C" int fhe_rns_ntt_set_stream(fhe_rns_ntt_t *h, void *stream) {
 // transform workspace of the general paths (full-width class, two-pass sizes).  Relinearisation on the general path sizes its digit
 // workspace by itself (bounded to 1 GiB, chunked).
 extern "C" int fhe_rns_ntt_reserve(fhe_rns_ntt_t *h, uint32_t batch) {
+    // The union of what every entry point asks of ensure_ws / ws2 / ws3 for `batch` units (each site cited), so that none of them allocates
+    // afterwards.  The key-switch workspaces depend on the digit count: the largest K of the key sets imported so far (import keys first).
     int rc = check_call(h, batch, "reserve"); if (rc) return rc;
-    const size_t S = (size_t)h->L * h->n * 32;
-    if ((rc = ensure_ws2(h, (size_t)batch * S))) return rc;            // >= 4 compact components of 8-byte residues, or one container component
-    if (h->sub_top && (rc = ensure_ws3(h, 2 * (size_t)batch * h->L * h->n * residue_bytes(h)))) return rc;   // two compact operands of a two-pass multiply
-    if (h->width == FHE_WIDTH_256 || h->sub_top) rc = ensure_ws(h, 5 * (size_t)batch * S);
-    else rc = ensure_ws(h, (size_t)batch * S / 2);                     // transformed b-side of the two-launch tensor product (2 compact components)
-    return rc;
+    const size_t polys = (size_t)batch * h->L, S = (size_t)h->L * h->n * 32, eb = residue_bytes(h), cbytes = polys * h->n * eb;
+    const bool lds_class = h->width != FHE_WIDTH_256 && !h->sub_top;
+    const uint32_t LK = h->L * (h->max_digits ? h->max_digits : 1);
+    size_t ws = 0, ws2 = (size_t)batch * S, ws3 = 0;                   // ws2: one container component (c2 of multiply + relinearise on the general path) ...
+    if (6 * cbytes > ws2) ws2 = 6 * cbytes;                            // ... or 4 compact accumulators + 2 rotated ones of a blind-rotation loop on the 8-byte fields
+    if (!lds_class) ws = 5 * (size_t)batch * S;                        // 4 transformed operands + one product (tensor product of the general / two-pass paths)
+    else ws = 2 * cbytes;                                              // transformed b-side of the two-launch tensor product (2 compact components)
+    if (h->max_composed_digits) {                                      // digit polynomials + two accumulators of the composed key switch (key sets without packed tables)
+        const size_t LK = (size_t)h->L * h->max_composed_digits;
+        size_t chunk = ((size_t)1 << 30) / ((LK + 2) * S); if (chunk < 1) chunk = 1; if (chunk > batch) chunk = batch;
+        if ((LK + 2) * chunk * S > ws) ws = (LK + 2) * chunk * S;
+    }
+    // (the few-ciphertext forms are taken by every call of at most split_pairs_polys / coop_polys limb polynomials: a smaller batch than the reserved one included)
+    if (lds_class && h->width == FHE_WIDTH_32 && h->split_pairs_polys) {            // few ciphertexts: one workgroup per digit pair, partial sums in the workspace
+        const size_t NP = (LK + 1) / 2, few = polys < h->split_pairs_polys ? polys : h->split_pairs_polys;
+        if (2 * few * NP * h->n * 4 > ws) ws = 2 * few * NP * h->n * 4;
+    }
+    if (h->sub_top) ws3 = 2 * cbytes;                                  // two compact operands of a two-pass multiply
+    if (lds_class && h->coop_polys && fhe_dev::lds_coop4_multiply((int)eb, (int)h->log_n))
+        ws3 = 7 * (polys < h->coop_polys ? polys : h->coop_polys) * h->n * 4;       // few polynomials over four workgroups each: 3 (multiply) / 7 (tensor product) block images per limb polynomial
+    if ((rc = ensure_ws(h, ws)) || (rc = ensure_ws2(h, ws2)) || (ws3 && (rc = ensure_ws3(h, ws3)))) return rc;
+    return ensure_aux_stream(h);                                       // second stream + events of the chunked pipelines
+}
+extern "C" int fhe_rns_ntt_workspace_bytes(const fhe_rns_ntt_t *h, uint64_t *bytes) {
+    if (!h || !bytes) return fail(FHE_ERR_INVALID_ARG, "workspace_bytes: null argument");
+    *bytes = (uint64_t)h->ws_bytes + h->ws2_bytes + h->ws3_bytes;
+    return FHE_OK;
 }
 extern "C" int fhe_rns_ntt_width_class(const fhe_rns_ntt_t *h) { return h ? h->width : fail(FHE_ERR_INVALID_ARG, "null handle"); }
 extern "C" int fhe_rns_ntt_forward(fhe_rns_ntt_t *h, void *d_data, uint32_t batch) {
@@ -1124,6 +1148,7 @@ extern "C" int fhe_relin_keys_create(fhe_rns_ntt_t *h, fhe_relin_keys_t **out, u
     fhe_relin_keys *rk = new (std::nothrow) fhe_relin_keys();
     if (!rk) return fail(FHE_ERR_INVALID_ARG, "out of host memory");
     rk->owner = h; rk->decomp_bits = decomp_bits; rk->K = K; rk->num_keys = num_keys;
+    if (K > h->max_digits) h->max_digits = K;                          // fhe_rns_ntt_reserve sizes the key-switch workspaces for it
     const size_t S = (size_t)h->L * h->n * 32;
     hipError_t e;
     if ((e = hipMalloc(&rk->d_kb, S * num_keys)) != hipSuccess || (e = hipMalloc(&rk->d_ka, S * num_keys)) != hipSuccess) {
@@ -1163,6 +1188,7 @@ extern "C" int fhe_relin_keys_create(fhe_rns_ntt_t *h, fhe_relin_keys_t **out, u
         }
     }
     if (rc) { fhe_relin_keys_destroy(rk); return rc; }
+    if (!rk->d_pkb && K > h->max_composed_digits) h->max_composed_digits = K;   // this key set runs the composed key switch (digit polynomials in the workspace)
     *out = rk;
     return FHE_OK;
 }

@@ -160,8 +160,11 @@ int fhe_rns_ntt_set_stream(fhe_rns_ntt_t *h, void *stream);
 int fhe_rns_ntt_width_class(const fhe_rns_ntt_t *h);
 /* Pre-sizes the library-owned workspaces for calls of up to `batch` units (fhe_ct_multiply_relin, fhe_blind_rotate, the general
  * paths), so that later calls never allocate: required before capturing such calls into a hipGraph, optional otherwise (the
- * workspaces grow on first use).  No counterpart in the reference, which mallocs and frees inside every multiply (src/ntt.cu:51-74). */
+ * workspaces grow on first use).  No counterpart in the reference, which mallocs and frees inside every multiply (src/ntt.cu:51-74).
+ * The key-switch workspaces depend on the digit count: import the key sets BEFORE reserving.  fhe_rns_ntt_workspace_bytes reports what
+ * the engine holds at the moment (device bytes in its three workspaces; tables and key sets are not counted). */
 int fhe_rns_ntt_reserve(fhe_rns_ntt_t *h, uint32_t batch);
+int fhe_rns_ntt_workspace_bytes(const fhe_rns_ntt_t *h, uint64_t *bytes);
 /* forward_rns / inverse_rns (src/ntt.cu:158-171): data [batch][L][n]; one launch for all limbs. */
 int fhe_rns_ntt_forward(fhe_rns_ntt_t *h, void *d_data, uint32_t batch);
 int fhe_rns_ntt_inverse(fhe_rns_ntt_t *h, void *d_data, uint32_t batch);

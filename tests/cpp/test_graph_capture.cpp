@@ -13,9 +13,12 @@
 #define HIP_OK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { std::fprintf(stderr, "HIP %s at line %d\n", hipGetErrorString(e_), __LINE__); std::exit(1); } } while (0)
 #define FHE_OK_(x) do { int rc_ = (x); if (rc_ != 0) { std::fprintf(stderr, "fhe error %d (%s) at line %d\n", rc_, fhe_hip_last_error(), __LINE__); std::exit(1); } } while (0)
 
-int main() {
-    const uint32_t n = 8192, L = 4, batch = 8, w = 16;
-    uint64_t primes[L]; FHE_OK_(fhe_find_ntt_primes(30, n, L, primes));
+// usage: test_graph_capture [prime_bits n batch]   (default 30 8192 8; the test also runs 30 8192 1 -- the few-ciphertext forms,
+// whose block images live in a third workspace -- and 40 16384 2 -- the 8-byte residues, whose blind-rotation loop keeps six compact polynomials)
+int main(int argc, char **argv) {
+    const uint32_t bits = argc > 3 ? (uint32_t)std::atoi(argv[1]) : 30, n = argc > 3 ? (uint32_t)std::atoi(argv[2]) : 8192, batch = argc > 3 ? (uint32_t)std::atoi(argv[3]) : 8;
+    constexpr uint32_t L = 4; const uint32_t w = 16;
+    uint64_t primes[L]; FHE_OK_(fhe_find_ntt_primes(bits, n, L, primes));
     uint64_t moduli[L][4]; for (uint32_t l = 0; l < L; l++) { moduli[l][0] = primes[l]; moduli[l][1] = moduli[l][2] = moduli[l][3] = 0; }
     fhe_rns_ntt_t *h = nullptr; FHE_OK_(fhe_rns_ntt_create(&h, n, moduli, L));
     hipStream_t s; HIP_OK(hipStreamCreate(&s));

@@ -65,10 +65,12 @@ def test_graph_capture_test_compiles(pkg):
 
 
 @pytest.mark.gpu
-def test_engine_launches_are_graph_capturable(pkg):
-    """Tensor product + relinearisation captured into a hipGraph on a caller-owned stream and replayed."""
+@pytest.mark.parametrize("shape", [(), ("30", "8192", "1"), ("40", "16384", "2")], ids=["n8192x30-batch8", "n8192x30-batch1", "n16384x40-batch2"])
+def test_engine_launches_are_graph_capturable(pkg, shape):
+    """Tensor product + relinearisation, the one-call multiply (after fhe_rns_ntt_reserve) and a blind-rotation loop captured into hipGraphs on a
+    caller-owned stream and replayed; batch 1 takes the few-ciphertext forms, the 40-bit primes the three-array kernels of the 8-byte residues."""
     exe = _build_graph_test(pkg)
-    res = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    res = subprocess.run([exe, *shape], capture_output=True, text=True, timeout=300)
     print(res.stdout)
     assert res.returncode == 0, res.stdout + res.stderr
     assert "graph capture ok" in res.stdout

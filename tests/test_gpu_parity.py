@@ -1373,3 +1373,34 @@ def test_ct_multiply_relin_matches_oracle(eng, oracle, monkeypatch, n, spec, w, 
         assert np.array_equal(buf.download(a0.shape), src)
     with pytest.raises(eng.FheError):
         e.ct_multiply_relin(rk, d[0], c1, d[0], d[1], d[2], d[3], batch)     # an output aliases an input
+
+
+@pytest.mark.parametrize("n,spec,w,batch", [(8192, ("bits", 30, 4), 16, 1), (8192, ("bits", 30, 4), 16, 24), (16384, ("bits", 30, 3), 30, 2), (4096, ("bits", 30, 4), 16, 300),
+                                            (4096, ("bits", 40, 3), 20, 2), (16384, ("bits", 40, 2), 20, 2), (2048, ("bits", 60, 2), 32, 3), (2048, ("bits", 64, 2), 32, 2),
+                                            (32768, ("bits", 30, 2), 16, 1), (65536, ("bits", 30, 1), 16, 1), (32768, ("bits", 40, 1), 20, 2),
+                                            (256, ("bits", 250, 1), 64, 2), (1024, ("bits", 120, 2), 40, 1)])
+@pytest.mark.parametrize("form", ["default", "composed"])
+def test_reserve_covers_every_entry_point(eng, monkeypatch, n, spec, w, batch, form):
+    """fhe_rns_ntt_reserve(h, batch) after the key import: no later call of up to `batch` units grows a library workspace (what a hipGraph capture
+    of those calls needs -- growth during capture is refused), on every width class, for few and many ciphertexts, two-pass sizes included."""
+    if form == "composed":
+        monkeypatch.setenv("FHE_HIP_NO_FUSED_KEYSWITCH", "1"); monkeypatch.setenv("FHE_HIP_NO_FUSED_BLIND_ROTATE", "1"); monkeypatch.setenv("FHE_HIP_NO_FUSED_CT_RELIN", "1")
+    moduli = _moduli(spec, n); L = len(moduli)
+    e = eng.RnsNttEngine(n, moduli)
+    K = e.relin_num_digits(w)
+    keys = [_up(eng, k) for k in _random_keys(moduli, n, L * K, 300)]
+    rk = e.import_relin_keys(w, keys, keys)
+    e.reserve(batch)
+    held = e.workspace_bytes()
+    assert held > 0
+    for nb in sorted({batch, 1, max(1, batch // 2)}):
+        x = rns_poly(77, moduli, n, nb)
+        d = [_up(eng, x) for _ in range(4)]; o = [eng.DeviceBuffer(x.nbytes) for _ in range(3)]
+        e.forward(d[0], nb); e.inverse(d[0], nb)
+        e.multiply(o[0], d[0], d[1], nb); e.multiply(o[0], d[0], d[0], nb)
+        e.ct_multiply(o[0], o[1], o[2], d[0], d[1], d[2], d[3], nb)
+        e.relinearize(rk, o[0], o[1], o[2], nb)
+        e.ct_multiply_relin(rk, o[0], o[1], d[0], d[1], d[2], d[3], nb)
+        sh = _up(eng, np.arange(3 * nb, dtype=np.uint32).reshape(3, nb) % (2 * n))
+        e.blind_rotate([rk] * 3, [rk] * 3, d[0], d[1], sh, o[0], o[1], nb)
+        assert e.workspace_bytes() == held, f"a call of {nb} units grew a workspace after reserve({batch})"
