@@ -76,8 +76,12 @@ __device__ __forceinline__ void wmont_column(uint64_t &lo, uint32_t &hi, const u
 template <int NL>
 __device__ __forceinline__ wint<NL> wmont(const wint<NL> &a, const wint<NL> &b, const wint<NL> &q, uint32_t qinv32) {
     constexpr int NW = 2 * NL;
-    uint32_t m[NW], tq[NW];
     wint<NL> t;
+#ifndef FHE_WIDE_COLUMN_BLOCKS      // round 3: the whole product as ONE asm block (wide_asm.inc: wmontc); -DFHE_WIDE_COLUMN_BLOCKS restores one block per column
+    if constexpr (NL == 4) wmontc_8(t.w, a.w, b.w, q.w, qinv32); else wmontc_4(t.w, a.w, b.w, q.w, qinv32);
+    return t;
+#endif
+    uint32_t m[NW], tq[NW];
     uint64_t lo = 0, bor = 0; uint32_t hi = 0;
     wmont_column<NL, 0>(lo, hi, a.w, b.w, q.w, m, t.w, tq, bor, qinv32);
     t.w[NW - 1] = (uint32_t)lo;                      // the sum is below 2q < 2^(32 NW): nothing above this word

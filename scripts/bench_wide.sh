@@ -1,12 +1,16 @@
 #!/bin/bash
-OUT=gpurun_out/matrix_wide.jsonl; : > $OUT
-run() { echo "== $*" >&2; timeout -k 10 600 python bench.py --no-cpu-baseline "$@" | grep '^{' >> $OUT || echo "FAILED: $*" >&2; }
-run --steps 3 --warmup 1 --op multiply --batch 128 --bits 64 --limbs 2
-run --steps 3 --warmup 1 --op multiply --batch 64 --bits 64 --limbs 4 --n 4096
-run --steps 3 --warmup 1 --op fwdinv --batch 128 --bits 64 --limbs 2
-python - <<PY
-import json
-for l in open("$OUT"):
-    d=json.loads(l); c=d["config"]; r=d["roofline"]
-    print(f'{c["op"]:9s} N={c["n"]:6d} L={c["limbs"]} bits={c["prime_bits"]:3d} B={c["batch_per_gpu"]:5d} {d["dtype"][:5]:5s} {d["value"]:12.1f} {d["unit"]:10s} {d["ms_per_step"]:9.4f} ms  {r["achieved"]:8.1f} GB/s  frac {r["frac"]:.3f}')
+# Full-width class (FHE_WIDTH_256) bench lines: 128-bit and 250-bit primes, multiply and forward+inverse.  usage: scripts/bench_wide.sh OUT.jsonl
+cd "$(dirname "$0")/.." || exit 1
+OUT=${1:-gpurun_out/wide.jsonl}; : > "$OUT"
+for bits in 250 120 128; do
+  L=2
+  for op in multiply fwdinv; do
+    python bench.py --no-extra-workloads --steps 5 --warmup 2 --op $op --batch 128 --bits $bits --limbs $L 2>/dev/null | tail -1 >> "$OUT"
+  done
+done
+python3 - "$OUT" <<'PY'
+import json, sys
+for l in open(sys.argv[1]):
+    d = json.loads(l); c = d["config"]
+    print(c["workload"][:70], round(d["value"]), d["roofline"]["frac"], d["roofline"].get("secondary", {}).get("frac"))
 PY
