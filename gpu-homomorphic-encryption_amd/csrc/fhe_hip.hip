@@ -256,6 +256,7 @@ struct fhe_rns_ntt {
     void *d_wlimbs = nullptr;           // FHE_WIDTH_256: WLimb<wide_nl>[L] for the NTT kernels of ntt_wide.hip.h (owned by d_tables)
     uint32_t sub_top = 0;               // word-sized classes beyond the LDS range: log2 n = 13 + sub_top (two-pass transforms), else 0
     int wide_nl = 0;                    // FHE_WIDTH_256: 64-bit limbs per residue in those kernels (2: q < 2^127, 4: q < 2^255)
+    bool wide_lazy = false;             // FHE_WIDTH_256: every modulus below 2^(64 wide_nl - 6): the lazy tile kernels (FHE_HIP_NO_WIDE_LAZY=1: the canonical ones; cross-check / A-B)
     bool wide_tiles = true;             // FHE_HIP_NO_WIDE_TILES=1: every stage as a global-memory pass (cross-check / A-B)
     bool no_square = false, single_transforms = false, global_twiddles = false, check_inputs = false, no_fused_keyswitch = false,
          no_word_conversions = false, no_fused_blind_rotate = false, no_fused_ct_relin = false, no_compact_blind_rotate = false, no_two_launch_ct = false, split_keyswitch = false, no_c2_compaction = false, no_prerotation = false;
@@ -531,6 +532,8 @@ static int create_impl(fhe_rns_ntt **out, uint32_t n, const uint64_t (*moduli)[4
     if (h->width != FHE_WIDTH_256 && h->log_n > (h->width == FHE_WIDTH_32 ? 15u : 14u)) h->sub_top = h->log_n - 13;
     if (!rc && h->width == FHE_WIDTH_256) {
         h->wide_nl = (max_bits <= 127 && floor_w != 256) ? 2 : 4;
+        // six spare bits above the largest modulus: the tile kernels run their butterflies without full reductions (ntt_wide.hip.h: wct_l)
+        h->wide_lazy = max_bits + 6 <= 64 * h->wide_nl && !getenv("FHE_HIP_NO_WIDE_LAZY");
         rc = h->wide_nl == 2 ? build_wlimbs<2>(h, cs) : build_wlimbs<4>(h, cs);
     }
     if (rc) { destroy_impl(h); return rc; }
@@ -621,8 +624,12 @@ static void wide_tile(fhe_rns_ntt *h, fhe_dev::u256 *dst, const fhe_dev::u256 *s
     for (uint32_t done = 0; done < polys;) {
         const uint32_t chunk = polys - done < chunk_max ? polys - done : chunk_max;
         const size_t o = (size_t)done * h->n;
-        hipLaunchKernelGGL((fhe_dev::wide_tile_kernel<NL, MODE>), dim3(chunk << tiles_log), dim3(fhe_dev::WT_T), 0, h->stream, dst + o, src + o,
-                           src2 ? src2 + o : nullptr, (const fhe_dev::WLimb<NL> *)h->d_wlimbs, h->L, h->log_n, scale);
+        if (h->wide_lazy)
+            hipLaunchKernelGGL((fhe_dev::wide_tile_kernel<NL, MODE, true>), dim3(chunk << tiles_log), dim3(fhe_dev::WT_T), 0, h->stream, dst + o, src + o,
+                               src2 ? src2 + o : nullptr, (const fhe_dev::WLimb<NL> *)h->d_wlimbs, h->L, h->log_n, scale);
+        else
+            hipLaunchKernelGGL((fhe_dev::wide_tile_kernel<NL, MODE, false>), dim3(chunk << tiles_log), dim3(fhe_dev::WT_T), 0, h->stream, dst + o, src + o,
+                               src2 ? src2 + o : nullptr, (const fhe_dev::WLimb<NL> *)h->d_wlimbs, h->L, h->log_n, scale);
         done += chunk;
     }
 }

@@ -101,6 +101,43 @@ template <int NL> __device__ __forceinline__ void wgs(wint<NL> &a, wint<NL> &b, 
     waddsub<NL>(a, b, q);
     b = wmont<NL>(b, w, q, qi);
 }
+// ---- the lazy class (round 3): q < 2^(64 NL - 6) ----------------------------------------------------------------------------------------
+// Six spare bits let a tile's forward transform run WITHOUT any reduction: with inputs below B q, T = b w R^-1 needs no closing subtraction
+// (T < q (1 + B q / R) < 2q), and (a, b) <- (a + T, a - T + 2q) stays below (B + 2) q: canonical input (B = 1), eleven stages -> below 23 q
+// < 2^(64 NL - 1).  Per forward butterfly that is 284 + 24 instructions instead of 302 + 48 (NL = 4).  The inverse (Gentleman-Sande) butterfly
+// doubles its sum, so it keeps one conditional subtraction per output, of 2q (values below 2q; the same waddsub block with 2q for q), and the
+// product without the closing subtraction.  Before anything leaves the kernel it is canonical again: the final scaling is a canonical Montgomery
+// product (input below 2q), and where there is none a ladder of conditional subtractions (16q, 8q, 4q, 2q, q) follows.
+template <int NL> __device__ __forceinline__ wint<NL> wmontl(const wint<NL> &a, const wint<NL> &b, const wint<NL> &q, uint32_t qinv32) {
+    wint<NL> t;
+    if constexpr (NL == 4) wmontl_8(t.w, a.w, b.w, q.w, qinv32); else wmontl_4(t.w, a.w, b.w, q.w, qinv32);
+    return t;
+}
+template <int NL> __device__ __forceinline__ wint<NL> wshl(const wint<NL> &q, int s) {     // q << s, 0 <= s < 32 (the caller knows it fits)
+    wint<NL> r;
+#pragma unroll
+    for (int i = 2 * NL - 1; i >= 0; i--) r.w[i] = s ? (q.w[i] << s) | (i ? q.w[i - 1] >> (32 - s) : 0u) : q.w[i];
+    return r;
+}
+// x[k] < 2^STEPS q  ->  x[k] < q: conditional subtractions of 2^(STEPS-1) q ... 2^LAST q (LAST = 0: canonical; LAST = 1: below 2q)
+template <int NL, int STEPS, int LAST = 0> __device__ __forceinline__ void wreduce(wint<NL> (&x)[8], const wint<NL> &q) {
+#pragma unroll
+    for (int s = STEPS - 1; s >= LAST; s--) {
+        const wint<NL> c = wshl<NL>(q, s);
+        if constexpr (NL == 4) { wcsub4_8(x[0].w, x[1].w, x[2].w, x[3].w, c.w); wcsub4_8(x[4].w, x[5].w, x[6].w, x[7].w, c.w); }
+        else { wcsub4_4(x[0].w, x[1].w, x[2].w, x[3].w, c.w); wcsub4_4(x[4].w, x[5].w, x[6].w, x[7].w, c.w); }
+    }
+}
+// forward: (a, b) <- (a + b w, a - b w + 2q), nothing reduced;  inverse: (a, b) <- (a + b mod 2q, (a - b mod 2q) w), inputs and outputs below 2q
+template <int NL> __device__ __forceinline__ void wct_l(wint<NL> &a, wint<NL> &b, const wint<NL> &w, const wint<NL> &q, const wint<NL> &q2, uint32_t qi) {
+    b = wmontl<NL>(b, w, q, qi);
+    if constexpr (NL == 4) wfree_8(a.w, b.w, q2.w); else wfree_4(a.w, b.w, q2.w);
+}
+template <int NL> __device__ __forceinline__ void wgs_l(wint<NL> &a, wint<NL> &b, const wint<NL> &w, const wint<NL> &q, const wint<NL> &q2, uint32_t qi) {
+    waddsub<NL>(a, b, q2);
+    b = wmontl<NL>(b, w, q, qi);
+}
+
 // a + b mod q alone (tensor product): the butterfly tail on copies
 template <int NL> __device__ __forceinline__ wint<NL> waddmod(wint<NL> a, wint<NL> b, const wint<NL> &q) { waddsub<NL>(a, b, q); return a; }
 
@@ -211,76 +248,78 @@ __device__ __forceinline__ void wt_get(const uint32_t *lds, uint32_t tid, wint<N
 
 // One register group: r-bits KHI .. KLO of pattern B0 (tile-index bits B0+KHI .. B0+KLO), forward order (descending).
 // gbase = index of the tile's first coefficient inside its polynomial.
-template <int NL, int B0, int K>
-__device__ __forceinline__ void wt_fwd_stage(wint<NL> (&x)[8], uint32_t ibase, uint32_t log_n, const WLimb<NL> &P, const wint<NL> &q) {
+template <int NL, int B0, int K, bool LZ>
+__device__ __forceinline__ void wt_fwd_stage(wint<NL> (&x)[8], uint32_t ibase, uint32_t log_n, const WLimb<NL> &P, const wint<NL> &q, const wint<NL> &q2) {
     constexpr int b = B0 + K;
     const wint<NL> *tw = P.tw + ((1u << (log_n - 1 - b)) + (ibase >> (b + 1)));
 #pragma unroll
     for (int r = 0; r < 8; r++) {
         if (r & (1 << K)) continue;
         const wint<NL> w = wload_t<NL>(tw + (r >> (K + 1)));
-        wct<NL>(x[r], x[r | (1 << K)], w, q, P.qinv32);
+        if constexpr (LZ) wct_l<NL>(x[r], x[r | (1 << K)], w, q, q2, P.qinv32);
+        else wct<NL>(x[r], x[r | (1 << K)], w, q, P.qinv32);
     }
 }
-template <int NL, int B0, int K>
-__device__ __forceinline__ void wt_inv_stage(wint<NL> (&x)[8], uint32_t ibase, uint32_t log_n, const WLimb<NL> &P, const wint<NL> &q) {
+template <int NL, int B0, int K, bool LZ>
+__device__ __forceinline__ void wt_inv_stage(wint<NL> (&x)[8], uint32_t ibase, uint32_t log_n, const WLimb<NL> &P, const wint<NL> &q, const wint<NL> &q2) {
     constexpr int b = B0 + K;
     const wint<NL> *tw = P.itw + ((1u << (log_n - 1 - b)) + (ibase >> (b + 1)));
 #pragma unroll
     for (int r = 0; r < 8; r++) {
         if (r & (1 << K)) continue;
         const wint<NL> w = wload_t<NL>(tw + (r >> (K + 1)));
-        wgs<NL>(x[r], x[r | (1 << K)], w, q, P.qinv32);
+        if constexpr (LZ) wgs_l<NL>(x[r], x[r | (1 << K)], w, q, q2, P.qinv32);
+        else wgs<NL>(x[r], x[r | (1 << K)], w, q, P.qinv32);
     }
 }
-template <int NL, int B0, int KHI, int KLO>
-__device__ __forceinline__ void wt_fwd_group(wint<NL> (&x)[8], uint32_t tid, uint32_t gbase, uint32_t log_n, const WLimb<NL> &P, const wint<NL> &q) {
+template <int NL, int B0, int KHI, int KLO, bool LZ>
+__device__ __forceinline__ void wt_fwd_group(wint<NL> (&x)[8], uint32_t tid, uint32_t gbase, uint32_t log_n, const WLimb<NL> &P, const wint<NL> &q, const wint<NL> &q2) {
     const uint32_t ibase = gbase + wt_base<B0>(tid);
-    wt_fwd_stage<NL, B0, KHI>(x, ibase, log_n, P, q);
-    if constexpr (KHI - 1 >= KLO) wt_fwd_stage<NL, B0, KHI - 1>(x, ibase, log_n, P, q);
-    if constexpr (KHI - 2 >= KLO) wt_fwd_stage<NL, B0, KHI - 2>(x, ibase, log_n, P, q);
+    wt_fwd_stage<NL, B0, KHI, LZ>(x, ibase, log_n, P, q, q2);
+    if constexpr (KHI - 1 >= KLO) wt_fwd_stage<NL, B0, KHI - 1, LZ>(x, ibase, log_n, P, q, q2);
+    if constexpr (KHI - 2 >= KLO) wt_fwd_stage<NL, B0, KHI - 2, LZ>(x, ibase, log_n, P, q, q2);
 }
-template <int NL, int B0, int KLO, int KHI>
-__device__ __forceinline__ void wt_inv_group(wint<NL> (&x)[8], uint32_t tid, uint32_t gbase, uint32_t log_n, const WLimb<NL> &P, const wint<NL> &q) {
+template <int NL, int B0, int KLO, int KHI, bool LZ>
+__device__ __forceinline__ void wt_inv_group(wint<NL> (&x)[8], uint32_t tid, uint32_t gbase, uint32_t log_n, const WLimb<NL> &P, const wint<NL> &q, const wint<NL> &q2) {
     const uint32_t ibase = gbase + wt_base<B0>(tid);
-    wt_inv_stage<NL, B0, KLO>(x, ibase, log_n, P, q);
-    if constexpr (KLO + 1 <= KHI) wt_inv_stage<NL, B0, KLO + 1>(x, ibase, log_n, P, q);
-    if constexpr (KLO + 2 <= KHI) wt_inv_stage<NL, B0, KLO + 2>(x, ibase, log_n, P, q);
+    wt_inv_stage<NL, B0, KLO, LZ>(x, ibase, log_n, P, q, q2);
+    if constexpr (KLO + 1 <= KHI) wt_inv_stage<NL, B0, KLO + 1, LZ>(x, ibase, log_n, P, q, q2);
+    if constexpr (KLO + 2 <= KHI) wt_inv_stage<NL, B0, KLO + 2, LZ>(x, ibase, log_n, P, q, q2);
 }
 
 // the low 11 stages of a forward transform: coefficients in pattern 8 (coalesced order) -> values in pattern 0 (8 consecutive per thread)
-template <int NL>
-__device__ __forceinline__ void wt_forward(wint<NL> (&x)[8], uint32_t *lds, uint32_t tid, uint32_t gbase, uint32_t log_n, const WLimb<NL> &P, const wint<NL> &q) {
-    wt_fwd_group<NL, 8, 2, 0>(x, tid, gbase, log_n, P, q);          // tile bits 10, 9, 8
+template <int NL, bool LZ>
+__device__ __forceinline__ void wt_forward(wint<NL> (&x)[8], uint32_t *lds, uint32_t tid, uint32_t gbase, uint32_t log_n, const WLimb<NL> &P, const wint<NL> &q, const wint<NL> &q2) {
+    wt_fwd_group<NL, 8, 2, 0, LZ>(x, tid, gbase, log_n, P, q, q2);          // tile bits 10, 9, 8
     wt_put<NL, 8>(lds, tid, x);
     __syncthreads();
     wt_get<NL, 5>(lds, tid, x);
-    wt_fwd_group<NL, 5, 2, 0>(x, tid, gbase, log_n, P, q);          // 7, 6, 5
+    wt_fwd_group<NL, 5, 2, 0, LZ>(x, tid, gbase, log_n, P, q, q2);          // 7, 6, 5
     wt_put<NL, 5>(lds, tid, x);                                     // the slots this thread just read: no barrier needed before
     __syncthreads();
     wt_get<NL, 2>(lds, tid, x);
-    wt_fwd_group<NL, 2, 2, 0>(x, tid, gbase, log_n, P, q);          // 4, 3, 2
+    wt_fwd_group<NL, 2, 2, 0, LZ>(x, tid, gbase, log_n, P, q, q2);          // 4, 3, 2
     wt_put<NL, 2>(lds, tid, x);
     __syncthreads();
     wt_get<NL, 0>(lds, tid, x);
-    wt_fwd_group<NL, 0, 1, 0>(x, tid, gbase, log_n, P, q);          // 1, 0
+    wt_fwd_group<NL, 0, 1, 0, LZ>(x, tid, gbase, log_n, P, q, q2);          // 1, 0
 }
 // the low 11 stages of an inverse transform: values in pattern 0 -> coefficients in pattern 8
-template <int NL>
-__device__ __forceinline__ void wt_inverse(wint<NL> (&x)[8], uint32_t *lds, uint32_t tid, uint32_t gbase, uint32_t log_n, const WLimb<NL> &P, const wint<NL> &q) {
-    wt_inv_group<NL, 0, 0, 1>(x, tid, gbase, log_n, P, q);          // tile bits 0, 1
+template <int NL, bool LZ>
+__device__ __forceinline__ void wt_inverse(wint<NL> (&x)[8], uint32_t *lds, uint32_t tid, uint32_t gbase, uint32_t log_n, const WLimb<NL> &P, const wint<NL> &q, const wint<NL> &q2) {
+    wt_inv_group<NL, 0, 0, 1, LZ>(x, tid, gbase, log_n, P, q, q2);          // tile bits 0, 1
     wt_put<NL, 0>(lds, tid, x);
     __syncthreads();
     wt_get<NL, 2>(lds, tid, x);
-    wt_inv_group<NL, 2, 0, 2>(x, tid, gbase, log_n, P, q);          // 2, 3, 4
+    wt_inv_group<NL, 2, 0, 2, LZ>(x, tid, gbase, log_n, P, q, q2);          // 2, 3, 4
     wt_put<NL, 2>(lds, tid, x);
     __syncthreads();
     wt_get<NL, 5>(lds, tid, x);
-    wt_inv_group<NL, 5, 0, 2>(x, tid, gbase, log_n, P, q);          // 5, 6, 7
+    wt_inv_group<NL, 5, 0, 2, LZ>(x, tid, gbase, log_n, P, q, q2);          // 5, 6, 7
     wt_put<NL, 5>(lds, tid, x);
     __syncthreads();
     wt_get<NL, 8>(lds, tid, x);
-    wt_inv_group<NL, 8, 0, 2>(x, tid, gbase, log_n, P, q);          // 8, 9, 10
+    wt_inv_group<NL, 8, 0, 2, LZ>(x, tid, gbase, log_n, P, q, q2);          // 8, 9, 10
 }
 
 enum { TILE_FWD = 0, TILE_INV = 1, TILE_MUL = 2 };
@@ -291,7 +330,8 @@ enum { TILE_FWD = 0, TILE_INV = 1, TILE_MUL = 2 };
 //   TILE_MUL : dst tile = inverse stages of (forward(src tile) .* forward(src2 tile)); the result carries R^-1 until the scaling
 //              by n^-1 R^2 (here when n = 2^11, else in the inverse top pass)
 // dst may alias src / src2 tile for tile: every workgroup loads its tiles completely before its first store.
-template <int NL, int MODE>
+// LZ: the lazy class (every q < 2^(64 NL - 6), see wct_l): same inputs, same canonical outputs, fewer instructions in between.
+template <int NL, int MODE, bool LZ>
 __global__ void __launch_bounds__(WT_T, 2)
 wide_tile_kernel(u256 *dst, const u256 *src, const u256 *src2, const WLimb<NL> *__restrict__ limbs, uint32_t L, uint32_t log_n, uint32_t scale) {
     __shared__ uint32_t lds[2 * NL * WT_N];
@@ -299,13 +339,15 @@ wide_tile_kernel(u256 *dst, const u256 *src, const u256 *src2, const WLimb<NL> *
     const uint32_t p = blockIdx.x >> (log_n - WT_LOG), tile = blockIdx.x & (tiles - 1);
     const WLimb<NL> &P = limbs[p % L];
     const wint<NL> q = P.q;
+    const wint<NL> q2 = LZ ? wshl<NL>(q, 1) : q;
     const uint32_t gbase = tile << WT_LOG;
     const size_t off = ((size_t)p << log_n) + gbase;
     wint<NL> x[8];
 #pragma unroll
     for (int r = 0; r < 8; r++) x[r] = wload_c<NL>(src + off + tid + r * WT_T);
     if constexpr (MODE == TILE_FWD) {
-        wt_forward<NL>(x, lds, tid, gbase, log_n, P, q);
+        wt_forward<NL, LZ>(x, lds, tid, gbase, log_n, P, q, q2);
+        if constexpr (LZ) wreduce<NL, 5>(x, q);                     // below 23 q -> canonical
         wt_put<NL, 0>(lds, tid, x);
         __syncthreads();
         wt_get<NL, 8>(lds, tid, x);                                 // back to the coalesced order for the store
@@ -313,22 +355,30 @@ wide_tile_kernel(u256 *dst, const u256 *src, const u256 *src2, const WLimb<NL> *
         wt_put<NL, 8>(lds, tid, x);
         __syncthreads();
         wt_get<NL, 0>(lds, tid, x);
-        wt_inverse<NL>(x, lds, tid, gbase, log_n, P, q);
+        wt_inverse<NL, LZ>(x, lds, tid, gbase, log_n, P, q, q2);
     } else {
         wint<NL> y[8];
 #pragma unroll
         for (int r = 0; r < 8; r++) y[r] = wload_c<NL>(src2 + off + tid + r * WT_T);   // issued early: hides under a's butterflies
-        wt_forward<NL>(x, lds, tid, gbase, log_n, P, q);
+        wt_forward<NL, LZ>(x, lds, tid, gbase, log_n, P, q, q2);
         __syncthreads();                                            // a's last exchange reads are over before b's first put
-        wt_forward<NL>(y, lds, tid, gbase, log_n, P, q);
+        wt_forward<NL, LZ>(y, lds, tid, gbase, log_n, P, q, q2);
+        if constexpr (LZ) {                                         // x < 23 q, y < 23 q -> y < 2q: the product is below q (1 + 46 q / R) < 2q
+            wreduce<NL, 5, 1>(y, q);
 #pragma unroll
-        for (int r = 0; r < 8; r++) x[r] = wmont<NL>(x[r], y[r], q, P.qinv32);
-        wt_inverse<NL>(x, lds, tid, gbase, log_n, P, q);            // starts in the pattern both transforms ended in: no exchange
+            for (int r = 0; r < 8; r++) x[r] = wmontl<NL>(x[r], y[r], q, P.qinv32);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 8; r++) x[r] = wmont<NL>(x[r], y[r], q, P.qinv32);
+        }
+        wt_inverse<NL, LZ>(x, lds, tid, gbase, log_n, P, q, q2);    // starts in the pattern both transforms ended in: no exchange
     }
-    if (MODE != TILE_FWD && scale) {
+    if (MODE != TILE_FWD && scale) {                                // canonical product: input below 2q (lazy) or q
         const wint<NL> c = scale == 2 ? P.ninv_r2 : P.ninv_m;
 #pragma unroll
         for (int r = 0; r < 8; r++) x[r] = wmont<NL>(x[r], c, q, P.qinv32);
+    } else if (LZ && MODE != TILE_FWD) {
+        wreduce<NL, 1>(x, q);                                       // below 2q -> canonical (the scaling happens in the top pass)
     }
 #pragma unroll
     for (int r = 0; r < 8; r++) wstore_c<NL>(dst + off + tid + r * WT_T, x[r]);

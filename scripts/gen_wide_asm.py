@@ -338,6 +338,53 @@ def gen_wmont(nw, lazy):
     return s + "}\n"
 
 
+def gen_free_tail(nw):
+    """(a, t) <- (a + t, a - t + c) modulo 2^(32 nw), no reduction: the forward butterfly tail of the lazy class (c = 2q; the true values stay
+    below 2^(32 nw), see ntt_wide.hip.h).  Three interleaved carry chains: d = a - t (into v), a += t (in place), t = d + c."""
+    A = lambda i: f"%{i}"
+    Tt = lambda i: f"%{nw + i}"
+    V = lambda i: f"%{2 * nw + i}"
+    C = lambda i: f"%{3 * nw + i}"
+    cA, cB, cC = "s[20:21]", "s[22:23]", "s[24:25]"
+    lines = []
+    for i in range(nw):
+        if i == 0:
+            lines += [f"v_sub_co_u32_e64 {V(i)}, {cA}, {A(i)}, {Tt(i)}", f"v_add_co_u32_e64 {A(i)}, {cB}, {A(i)}, {Tt(i)}",
+                      f"v_add_co_u32_e64 {Tt(i)}, {cC}, {V(i)}, {C(i)}"]
+        else:
+            lines += [f"v_subb_co_u32_e64 {V(i)}, {cA}, {A(i)}, {Tt(i)}, {cA}", f"v_addc_co_u32_e64 {A(i)}, {cB}, {A(i)}, {Tt(i)}, {cB}",
+                      f"v_addc_co_u32_e64 {Tt(i)}, {cC}, {V(i)}, {C(i)}, {cC}"]
+    outs = [f'"+v"(a[{i}])' for i in range(nw)] + [f'"+v"(t[{i}])' for i in range(nw)] + [f'"=&v"(v[{i}])' for i in range(nw)]
+    ins = [f'"v"(c[{i}])' for i in range(nw)]
+    s = (f"// (a, t) <- (a + t, a - t + c) mod 2^{32 * nw}: {len(lines)} instructions\n"
+         f"__device__ __forceinline__ void wfree_{nw}(uint32_t (&a)[{nw}], uint32_t (&t)[{nw}], const uint32_t (&c)[{nw}]) {{\n    uint32_t v[{nw}];\n")
+    s += asm_block(lines, outs, ins, ["s20", "s21", "s22", "s23", "s24", "s25"])
+    return s + "}\n"
+
+
+def gen_csub4(nw):
+    """x_k <- x_k >= c ? x_k - c : x_k for four values at once (four interleaved borrow chains: no wait states), c < 2^(32 nw)."""
+    SPK = ["s[20:21]", "s[22:23]", "s[24:25]", "s[26:27]"]
+    X = lambda k, i: f"%{k * nw + i}"
+    D = lambda k, i: f"%{4 * nw + k * nw + i}"
+    C = lambda i: f"%{8 * nw + i}"
+    lines = []
+    for i in range(nw):
+        for k in range(4):
+            lines.append(f"v_sub_co_u32_e64 {D(k, i)}, {SPK[k]}, {X(k, i)}, {C(i)}" if i == 0 else
+                         f"v_subb_co_u32_e64 {D(k, i)}, {SPK[k]}, {X(k, i)}, {C(i)}, {SPK[k]}")
+    for k in range(4):
+        for i in range(nw):
+            lines.append(f"v_cndmask_b32_e64 {X(k, i)}, {D(k, i)}, {X(k, i)}, {SPK[k]}")      # borrow set (x < c): keep x
+    outs = [f'"+v"(x{k}[{i}])' for k in range(4) for i in range(nw)] + [f'"=&v"(d{k}[{i}])' for k in range(4) for i in range(nw)]
+    ins = [f'"v"(c[{i}])' for i in range(nw)]
+    args = ", ".join(f"uint32_t (&x{k})[{nw}]" for k in range(4))
+    s = (f"// four conditional subtractions of the same constant: {len(lines)} instructions\n"
+         f"__device__ __forceinline__ void wcsub4_{nw}({args}, const uint32_t (&c)[{nw}]) {{\n    uint32_t d0[{nw}], d1[{nw}], d2[{nw}], d3[{nw}];\n")
+    s += asm_block(lines, outs, ins, ["s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27"])
+    return s + "}\n"
+
+
 def dispatcher(name, maxc, extra_params, extra_args):
     s = f"template <int CNT>\n__device__ __forceinline__ void {name}(uint64_t &lo, uint32_t &hi{extra_params}, const uint32_t (&x)[16], const uint32_t (&y)[16]) {{\n"
     for c in range(1, maxc + 1):
@@ -361,6 +408,8 @@ def main():
         parts.append(gen_addsub(nw))
         parts.append(gen_wmont(nw, False))
         parts.append(gen_wmont(nw, True))
+        parts.append(gen_free_tail(nw))
+        parts.append(gen_csub4(nw))
     open(OUT, "w").write("\n".join(parts))
     print("wrote", OUT)
 

@@ -39,6 +39,9 @@ while time.time() - t0 < budget:
     os.environ.pop("FHE_HIP_SMALL_BATCH_POLYS", None); os.environ.pop("FHE_HIP_COOP_POLYS", None)
     os.environ["FHE_HIP_FORCE_WIDTH"] = "256"
     wide = pkg.RnsNttEngine(n, moduli)
+    os.environ["FHE_HIP_NO_WIDE_LAZY"] = "1"           # its canonical tile kernels (the default engine takes the lazy ones: these moduli leave six spare bits)
+    wide_c = pkg.RnsNttEngine(n, moduli)
+    os.environ.pop("FHE_HIP_NO_WIDE_LAZY", None)
     os.environ["FHE_HIP_FORCE_WIDTH"] = "128"          # the same class on two 64-bit limbs (R = 2^128)
     wide2 = pkg.RnsNttEngine(n, moduli)
     os.environ["FHE_HIP_NO_WIDE_TILES"] = "1"          # and with every stage as a global-memory pass (no LDS tiles)
@@ -52,7 +55,7 @@ while time.time() - t0 < budget:
     info = dict(n=n, bits=bits, L=L, batch=batch, seed=seed)
     ref = {}
     for rep in range(3):
-        for eng, tag in ((wide, "wide"), (fast, "fast"), (fast_tp, "fast-throughput-kernel"), (fast_lat, "fast-latency-kernel"), (wide2, "wide-2-limb"), (wide2p, "wide-2-limb-passes"), (fast, "fast"))[:7 if rep == 0 else 4]:
+        for eng, tag in ((wide, "wide"), (fast, "fast"), (fast_tp, "fast-throughput-kernel"), (fast_lat, "fast-latency-kernel"), (wide2, "wide-2-limb"), (wide2p, "wide-2-limb-passes"), (wide_c, "wide-canonical-tiles"), (fast, "fast"))[:8 if rep == 0 else 4]:
             d = [pkg.DeviceBuffer.from_numpy(v) for v in x]
             o = [pkg.DeviceBuffer(x[0].nbytes) for _ in range(3)]
             eng.multiply(o[0], d[0], d[1], batch); launches += 1

@@ -1404,3 +1404,54 @@ def test_reserve_covers_every_entry_point(eng, monkeypatch, n, spec, w, batch, f
         sh = _up(eng, np.arange(3 * nb, dtype=np.uint32).reshape(3, nb) % (2 * n))
         e.blind_rotate([rk] * 3, [rk] * 3, d[0], d[1], sh, o[0], o[1], nb)
         assert e.workspace_bytes() == held, f"a call of {nb} units grew a workspace after reserve({batch})"
+
+
+def _largest_ntt_primes(bits, n, count):
+    """The `count` largest primes below 2^bits with q = 1 (mod 2n): the top of a width class's range."""
+    out, step = [], 2 * n
+    q = ((1 << bits) // step) * step + 1
+    while q >= (1 << bits):
+        q -= step
+    while len(out) < count:
+        if nm.is_prime(q):
+            out.append(q)
+        q -= step
+    return out
+
+
+@pytest.mark.parametrize("n,bits,L,lazy", [(2048, 250, 2, True), (8192, 250, 1, True), (4096, 122, 2, True), (2048, 122, 1, True), (16384, 250, 1, True),
+                                           (2048, 251, 1, False), (2048, 123, 1, False), (2048, 255, 1, False)])
+def test_full_width_lazy_tiles_at_the_top_of_their_range(eng, oracle, monkeypatch, n, bits, L, lazy):
+    """The full-width tile kernels skip reductions when every modulus leaves six spare bits (q < 2^250 on four limbs, q < 2^122 on two):
+    forward butterflies unreduced (values below 23 q), inverse ones below 2q, canonical again before anything is stored.  The LARGEST primes of
+    each range, operands at the top of [0, q): the lazy kernels, the canonical ones (FHE_HIP_NO_WIDE_LAZY=1) and the oracle agree bit for bit;
+    one bit above the threshold the engine stays on the canonical kernels (same results either way)."""
+    moduli = _largest_ntt_primes(bits, n, L)
+    assert all(q.bit_length() == bits for q in moduli)
+    e = eng.RnsNttEngine(n, moduli)
+    monkeypatch.setenv("FHE_HIP_NO_WIDE_LAZY", "1")
+    e_canon = eng.RnsNttEngine(n, moduli)
+    monkeypatch.delenv("FHE_HIP_NO_WIDE_LAZY")
+    assert e.width_class == eng.WIDTH_256
+    rp = oracle.RnsPlan(n, moduli)
+    batch = 3
+    a = rns_poly(11, moduli, n, batch); b = rns_poly(12, moduli, n, batch)
+    for l, q in enumerate(moduli):                       # slot 1: every coefficient q - 1; slot 2: q - 1 and 0 alternating against q - 1 and 1
+        top = np.array([(q - 1) >> (64 * w) & (2**64 - 1) for w in range(4)], dtype=np.uint64)
+        a[1, l, :, :] = top; b[1, l, :, :] = top
+        a[2, l, ::2, :] = top; a[2, l, 1::2, :] = 0
+        b[2, l, :, :] = top; b[2, l, 1::2, :] = 0; b[2, l, 1::2, 0] = 1
+    shape = a.shape
+    want_f, want_i, want_m = rp.forward(a, threads=8), rp.inverse(b, threads=8), rp.polymul(a, b, threads=8)
+    for engine in (e, e_canon):
+        d = _up(eng, a); engine.forward(d, batch)
+        assert np.array_equal(d.download(shape), want_f)
+        engine.inverse(d, batch)
+        assert np.array_equal(d.download(shape), a)
+        d = _up(eng, b); engine.inverse(d, batch)
+        assert np.array_equal(d.download(shape), want_i)
+        dA, dB, dR = _up(eng, a), _up(eng, b), eng.DeviceBuffer(a.nbytes)
+        engine.multiply(dR, dA, dB, batch)
+        assert np.array_equal(dR.download(shape), want_m)
+        engine.multiply(dA, dA, dA, batch)               # square, in place
+        assert np.array_equal(dA.download(shape), rp.polymul(a, a, threads=8))
