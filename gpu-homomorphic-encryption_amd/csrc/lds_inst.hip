@@ -27,10 +27,14 @@ template <class F, int LOGN>
 static bool launch_coop4_multiply(const LdsArgs &A, const Limb<F> *limbs) {
     using E = typename F::E;
     if constexpr (lds_coop4_multiply(sizeof(E), LOGN)) {
-        const dim3 grid(A.polys * 4), block(Coop4<F, LOGN>::T);
-        hipLaunchKernelGGL((ntt_multiply4_top_kernel<F, LOGN>), grid, block, 0, A.stream, (const char *)A.a0, (const char *)A.b0, (E *)A.coop_ws, limbs, A.L, A.b_polys ? 1u : 0u);
+        const dim3 grid(A.polys * 4), cgrid(A.polys * Coop4<F, LOGN>::CWG), block(Coop4<F, LOGN>::T);      // blocks: four per limb polynomial; columns: CWG
+        hipLaunchKernelGGL((ntt_multiply4_top_kernel<F, LOGN>), cgrid, block, 0, A.stream, (const char *)A.a0, (const char *)A.b0, (E *)A.coop_ws, limbs, A.L, A.b_polys ? 1u : 0u);
+#ifndef FHE_COOP_ONE_GROUP
+        hipLaunchKernelGGL((ntt_multiply4_block_kernel<F, LOGN>), grid, dim3(2 * Coop4<F, LOGN>::T), 0, A.stream, (E *)A.coop_ws, limbs, A.L);   // two groups: the forward transforms side by side
+#else
         hipLaunchKernelGGL((ntt_multiply4_block_kernel<F, LOGN>), grid, block, 0, A.stream, (E *)A.coop_ws, limbs, A.L);
-        hipLaunchKernelGGL((ntt_multiply4_last_kernel<F, LOGN>), grid, block, 0, A.stream, (char *)A.r0, (const E *)A.coop_ws, limbs, A.L);
+#endif
+        hipLaunchKernelGGL((ntt_multiply4_last_kernel<F, LOGN>), cgrid, block, 0, A.stream, (char *)A.r0, (const E *)A.coop_ws, limbs, A.L);
         return true;
     } else {
         return false;
@@ -42,10 +46,15 @@ static bool launch_coop4_ct_multiply(const LdsArgs &A, const Limb<F> *limbs) {
     using E = typename F::E;
     if constexpr (lds_coop4_multiply(sizeof(E), LOGN)) {
         const dim3 block(Coop4<F, LOGN>::T);
-        hipLaunchKernelGGL((ntt_ct4_top_kernel<F, LOGN>), dim3(A.polys * 4, 4), block, 0, A.stream, (const char *)A.a0, (const char *)A.a1, (const char *)A.b0,
+        hipLaunchKernelGGL((ntt_ct4_top_kernel<F, LOGN>), dim3(A.polys * Coop4<F, LOGN>::CWG, 4), block, 0, A.stream, (const char *)A.a0, (const char *)A.a1, (const char *)A.b0,
                            (const char *)A.b1, (E *)A.coop_ws, limbs, A.L);
-        hipLaunchKernelGGL((ntt_ct4_block_kernel<F, LOGN>), dim3(A.polys * 4), block, 0, A.stream, (E *)A.coop_ws, limbs, A.L);
-        hipLaunchKernelGGL((ntt_ct4_last_kernel<F, LOGN>), dim3(A.polys * 4, 3), block, 0, A.stream, (E *)A.r0, (E *)A.r1, (E *)A.r2, (const E *)A.coop_ws, limbs, A.L);
+#ifndef FHE_COOP_ONE_GROUP
+        if constexpr (LOGN == 13)      // four groups of threads: the four forward transforms side by side, three inverses side by side
+            hipLaunchKernelGGL((ntt_ct4_block_kernel<F, LOGN>), dim3(A.polys * 4), dim3(4 * Coop4<F, LOGN>::T), 0, A.stream, (E *)A.coop_ws, limbs, A.L);
+        else
+#endif
+        hipLaunchKernelGGL((ntt_ct4_block1_kernel<F, LOGN>), dim3(A.polys * 4), block, 0, A.stream, (E *)A.coop_ws, limbs, A.L);
+        hipLaunchKernelGGL((ntt_ct4_last_kernel<F, LOGN>), dim3(A.polys * Coop4<F, LOGN>::CWG, 3), block, 0, A.stream, (E *)A.r0, (E *)A.r1, (E *)A.r2, (const E *)A.coop_ws, limbs, A.L);
         return true;
     } else {
         return false;

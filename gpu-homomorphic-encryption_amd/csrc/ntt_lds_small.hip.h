@@ -317,7 +317,14 @@ struct Coop4 {
     using S = Cfg16<LOGS>;
     static constexpr int T = S::T;                        // threads per workgroup (128 / 256)
     static constexpr int NS = 1 << LOGS;                  // coefficients per block = columns of the top stages
-    static constexpr int CPT = NS / 4 / T;                // columns per thread in phases 1 and 3 (= 4)
+#ifndef FHE_COOP_COLUMNS_PER_THREAD
+#define FHE_COOP_COLUMNS_PER_THREAD 1
+#endif
+    // phases 1 and 3 work on COLUMNS (coefficients c, c + N/4, c + N/2, c + 3N/4) and can be cut anywhere: one column per thread = 16 workgroups per limb
+    // polynomial, so that a CU ingests 32 KiB of operand containers instead of 128 KiB (-DFHE_COOP_COLUMNS_PER_THREAD=4: the first form, four workgroups)
+    static constexpr int CPT = FHE_COOP_COLUMNS_PER_THREAD;
+    static constexpr int CWG = NS / (T * CPT);            // column workgroups per limb polynomial (16 or 4)
+    static_assert(CWG * T * CPT == NS, "columns per thread must divide the columns of a workgroup");
 };
 // ws: per polynomial three compact polynomials (top(a), top(b), block results)
 template <class F, int LOGN>
@@ -326,7 +333,7 @@ ntt_multiply4_top_kernel(const char *a, const char *b, typename F::E *ws, const 
     using K = Coop4<F, LOGN>;
     using E = typename F::E;
     constexpr int NS = K::NS, T = K::T, N = 1 << LOGN;
-    const uint32_t tid = threadIdx.x, p = blockIdx.x >> 2, k = blockIdx.x & 3, limb = p % L;
+    const uint32_t tid = threadIdx.x, p = blockIdx.x / K::CWG, k = blockIdx.x % K::CWG, limb = p % L;
     const Limb<F> P = limbs[limb];
     E *wa = ws + (size_t)p * (3 * N), *wb = wa + N;
     const typename F::TW t1 = load_global(P.tw + 1), t2 = load_global(P.tw + 2), t3 = load_global(P.tw + 3);
@@ -334,13 +341,13 @@ ntt_multiply4_top_kernel(const char *a, const char *b, typename F::E *ws, const 
     E xa[K::CPT][4], xb[K::CPT][4];
 #pragma unroll
     for (int m = 0; m < K::CPT; m++) {
-        const uint32_t c = k * (NS / 4) + tid + m * T;
+        const uint32_t c = k * (K::CPT * T) + tid + m * T;
 #pragma unroll
         for (int q = 0; q < 4; q++) { xa[m][q] = F::load_low(pa + (size_t)(q * NS + c) * 32); xb[m][q] = F::load_low(pb + (size_t)(q * NS + c) * 32); }
     }
 #pragma unroll
     for (int m = 0; m < K::CPT; m++) {
-        const uint32_t c = k * (NS / 4) + tid + m * T;
+        const uint32_t c = k * (K::CPT * T) + tid + m * T;
         F::fwd_bfly(xa[m][0], xa[m][2], t1, P); F::fwd_bfly(xa[m][1], xa[m][3], t1, P);      // index bit LOGN-1
         F::fwd_bfly(xa[m][0], xa[m][1], t2, P); F::fwd_bfly(xa[m][2], xa[m][3], t3, P);      // index bit LOGN-2
         F::fwd_bfly(xb[m][0], xb[m][2], t1, P); F::fwd_bfly(xb[m][1], xb[m][3], t1, P);
@@ -352,6 +359,42 @@ ntt_multiply4_top_kernel(const char *a, const char *b, typename F::E *ws, const 
         }
     }
 }
+// Phase 2 with the two forward transforms SIDE BY SIDE: the workgroup is two groups of T threads (group 0: the a block, group 1: the b block, each with
+// its own LDS image); NTT(b) crosses to group 0 through group 1's image in register order, group 0 multiplies and runs the inverse.  The critical path is
+// two transforms instead of three.  Group 1 walks through the inverse's barriers on its stale registers (its waves sit on other SIMDs) and stores nothing.
+// Same arithmetic per coefficient as the one-group form (-DFHE_COOP_ONE_GROUP): a-side canonical, b-side lazy, pw_mul.
+#ifndef FHE_COOP_ONE_GROUP
+template <class F, int LOGN>
+__global__ void __launch_bounds__(2 << (LOGN - 6))
+ntt_multiply4_block_kernel(typename F::E *ws, const Limb<F> *__restrict__ limbs, uint32_t L) {
+    using K = Coop4<F, LOGN>;
+    using E = typename F::E;
+    constexpr int LOGS = K::LOGS, NS = K::NS, T = K::T, N = 1 << LOGN;
+    __shared__ E lds[2][NS];
+    const uint32_t g = threadIdx.x / T, tid = threadIdx.x % T, p = blockIdx.x >> 2, k = blockIdx.x & 3;      // g is wave-uniform (T is a multiple of 64)
+    const Limb<F> P = limbs[p % L];
+    E *wa = ws + (size_t)p * (3 * N), *wb = wa + N, *wr = wb + N;
+    Twiddles16<F, LOGS> W;
+    W.template load<true>(tid, P, 4 + k);
+    E x[16], y[16];
+    const E *src = g ? wb : wa;
+#pragma unroll
+    for (int r = 0; r < 16; r++) x[r] = src[k * NS + tid + r * T];
+    fwd_core16<F, LOGS>(x, lds[g], tid, P, W);
+    if (g) put16<P16Z<LOGS>>(lds[1], tid, x);         // the slots this thread read last
+    __syncthreads();
+    if (!g) {
+        get16<P16Z<LOGS>>(lds[1], tid, y);
+#pragma unroll
+        for (int r = 0; r < 16; r++) x[r] = F::pw_mul(F::canon_fwd(x[r], P.q, P.q2, P.qinv), y[r], P.q, P.qinv);   // carries 2^-W until the last stage (ninv_r constants)
+    }
+    inv_core16<F, LOGS, true>(x, lds[g], tid, P, W, P.ninv, P.ninv_s, P.ninvw, P.ninvw_s);
+    if (!g) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) wr[k * NS + tid + r * T] = F::canon_inv(x[r], P.q);
+    }
+}
+#else
 template <class F, int LOGN>
 __global__ void __launch_bounds__(1 << (LOGN - 6))
 ntt_multiply4_block_kernel(typename F::E *ws, const Limb<F> *__restrict__ limbs, uint32_t L) {
@@ -378,20 +421,21 @@ ntt_multiply4_block_kernel(typename F::E *ws, const Limb<F> *__restrict__ limbs,
 #pragma unroll
     for (int r = 0; r < 16; r++) wr[k * NS + tid + r * T] = F::canon_inv(x[r], P.q);
 }
+#endif
 template <class F, int LOGN>
 __global__ void __launch_bounds__(1 << (LOGN - 6))
 ntt_multiply4_last_kernel(char *res, const typename F::E *ws, const Limb<F> *__restrict__ limbs, uint32_t L) {
     using K = Coop4<F, LOGN>;
     using E = typename F::E;
     constexpr int NS = K::NS, T = K::T, N = 1 << LOGN;
-    const uint32_t tid = threadIdx.x, p = blockIdx.x >> 2, k = blockIdx.x & 3;
+    const uint32_t tid = threadIdx.x, p = blockIdx.x / K::CWG, k = blockIdx.x % K::CWG;
     const Limb<F> P = limbs[p % L];
     const E *wr = ws + (size_t)p * (3 * N) + 2 * N;
     const typename F::TW i2 = load_global(P.itw + 2), i3 = load_global(P.itw + 3);
     typename F::V16 *out = reinterpret_cast<typename F::V16 *>(res + (size_t)p * (N * 32));
 #pragma unroll
     for (int m = 0; m < K::CPT; m++) {
-        const uint32_t c = k * (NS / 4) + tid + m * T;
+        const uint32_t c = k * (K::CPT * T) + tid + m * T;
         E v[4];
 #pragma unroll
         for (int q = 0; q < 4; q++) v[q] = wr[q * NS + c];
@@ -415,8 +459,8 @@ ntt_ct4_top_kernel(const char *a0, const char *a1, const char *b0, const char *b
     using K = Coop4<F, LOGN>;
     using E = typename F::E;
     constexpr int NS = K::NS, T = K::T, N = 1 << LOGN;
-    const uint32_t tid = threadIdx.x, p = blockIdx.x >> 2, k = blockIdx.x & 3;
-    const uint32_t which = blockIdx.y;                    // operand 0..3 (grid.y = 4): 16 workgroups per (ciphertext, limb) in this phase
+    const uint32_t tid = threadIdx.x, p = blockIdx.x / K::CWG, k = blockIdx.x % K::CWG;
+    const uint32_t which = blockIdx.y;                    // operand 0..3 (grid.y = 4)
     const Limb<F> P = limbs[p % L];
     const char *src = (which == 0 ? a0 : which == 1 ? a1 : which == 2 ? b0 : b1) + (size_t)p * (N * 32);
     E *w = ws + (size_t)p * (7 * N) + (size_t)which * N;
@@ -424,13 +468,13 @@ ntt_ct4_top_kernel(const char *a0, const char *a1, const char *b0, const char *b
     E x[K::CPT][4];
 #pragma unroll
     for (int m = 0; m < K::CPT; m++) {
-        const uint32_t c = k * (NS / 4) + tid + m * T;
+        const uint32_t c = k * (K::CPT * T) + tid + m * T;
 #pragma unroll
         for (int q = 0; q < 4; q++) x[m][q] = F::load_low(src + (size_t)(q * NS + c) * 32);
     }
 #pragma unroll
     for (int m = 0; m < K::CPT; m++) {
-        const uint32_t c = k * (NS / 4) + tid + m * T;
+        const uint32_t c = k * (K::CPT * T) + tid + m * T;
         F::fwd_bfly(x[m][0], x[m][2], t1, P); F::fwd_bfly(x[m][1], x[m][3], t1, P);
         F::fwd_bfly(x[m][0], x[m][1], t2, P); F::fwd_bfly(x[m][2], x[m][3], t3, P);
 #pragma unroll
@@ -439,7 +483,7 @@ ntt_ct4_top_kernel(const char *a0, const char *a1, const char *b0, const char *b
 }
 template <class F, int LOGN>
 __global__ void __launch_bounds__(1 << (LOGN - 6))
-ntt_ct4_block_kernel(typename F::E *ws, const Limb<F> *__restrict__ limbs, uint32_t L) {
+ntt_ct4_block1_kernel(typename F::E *ws, const Limb<F> *__restrict__ limbs, uint32_t L) {
     using K = Coop4<F, LOGN>;
     using E = typename F::E;
     constexpr int LOGS = K::LOGS, NS = K::NS, T = K::T, N = 1 << LOGN;
@@ -482,6 +526,58 @@ ntt_ct4_block_kernel(typename F::E *ws, const Limb<F> *__restrict__ limbs, uint3
 #pragma unroll
     for (int r = 0; r < 16; r++) w[6 * N + k * NS + tid + r * T] = F::canon_inv(B0[r], P.q);
 }
+// Phase 2 of the tensor product with its four forward transforms SIDE BY SIDE (N = 2^13: four groups of 128 threads, one operand block and one LDS image
+// each; at N = 2^14 four groups would be 1024 threads at 128 VGPRs, so that size keeps the one-group form, ntt_ct4_block1_kernel).  The transformed blocks
+// cross through the images in register order; groups 0, 1, 2 form c0 = a0 b0, c1 = a0 b1 + a1 b0, c2 = a1 b1 and run one inverse each (group 3 walks the
+// barriers).  Critical path: two transforms instead of seven.  Same arithmetic per coefficient: a-side canonical, b-side lazy, pw_mul / pw_mul2.
+template <class F, int LOGN>
+__global__ void __launch_bounds__(4 << (LOGN - 6))
+ntt_ct4_block_kernel(typename F::E *ws, const Limb<F> *__restrict__ limbs, uint32_t L) {
+    using K = Coop4<F, LOGN>;
+    using E = typename F::E;
+    constexpr int LOGS = K::LOGS, NS = K::NS, T = K::T, N = 1 << LOGN;
+    __shared__ E lds[4][NS];
+    const uint32_t g = threadIdx.x / T, tid = threadIdx.x % T, p = blockIdx.x >> 2, k = blockIdx.x & 3;      // g is wave-uniform
+    const Limb<F> P = limbs[p % L];
+    E *w = ws + (size_t)p * (7 * N);
+    Twiddles16<F, LOGS> W;
+    W.template load<true>(tid, P, 4 + k);
+    E x[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) x[r] = w[(size_t)g * N + k * NS + tid + r * T];      // g = 0..3: a0, a1, b0, b1
+    fwd_core16<F, LOGS>(x, lds[g], tid, P, W);
+    if (g < 2) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) x[r] = F::canon_fwd(x[r], P.q, P.q2, P.qinv);    // canonical a-side, lazy b-side
+    }
+    put16<P16Z<LOGS>>(lds[g], tid, x);                    // the slots this thread read last
+    __syncthreads();
+    if (g == 0) {                                         // c0 = a0 b0
+        E v0[16];
+        get16<P16Z<LOGS>>(lds[2], tid, v0);
+#pragma unroll
+        for (int r = 0; r < 16; r++) x[r] = F::pw_mul(x[r], v0[r], P.q, P.qinv);
+    } else if (g == 1) {                                  // c1 = a0 b1 + a1 b0 (x = a1)
+        E u0[16], v0[16], v1[16];
+        get16<P16Z<LOGS>>(lds[0], tid, u0);
+        get16<P16Z<LOGS>>(lds[2], tid, v0);
+        get16<P16Z<LOGS>>(lds[3], tid, v1);
+#pragma unroll
+        for (int r = 0; r < 16; r++) x[r] = F::pw_mul2(u0[r], v1[r], x[r], v0[r], P.q, P.q2, P.qinv);
+    } else if (g == 2) {                                  // c2 = a1 b1
+        E u1[16], v1[16];
+        get16<P16Z<LOGS>>(lds[1], tid, u1);
+        get16<P16Z<LOGS>>(lds[3], tid, v1);
+#pragma unroll
+        for (int r = 0; r < 16; r++) x[r] = F::pw_mul(u1[r], v1[r], P.q, P.qinv);
+    }
+    __syncthreads();                                      // every image has been read before the inverse transforms overwrite them
+    inv_core16<F, LOGS, true>(x, lds[g], tid, P, W, P.ninv, P.ninv_s, P.ninvw, P.ninvw_s);
+    if (g < 3) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) w[(size_t)(4 + g) * N + k * NS + tid + r * T] = F::canon_inv(x[r], P.q);
+    }
+}
 template <class F, int LOGN>
 __global__ void __launch_bounds__(1 << (LOGN - 6))
 ntt_ct4_last_kernel(typename F::E *__restrict__ c0, typename F::E *__restrict__ c1, typename F::E *__restrict__ c2, const typename F::E *ws,
@@ -489,14 +585,14 @@ ntt_ct4_last_kernel(typename F::E *__restrict__ c0, typename F::E *__restrict__ 
     using K = Coop4<F, LOGN>;
     using E = typename F::E;
     constexpr int NS = K::NS, T = K::T, N = 1 << LOGN;
-    const uint32_t tid = threadIdx.x, p = blockIdx.x >> 2, k = blockIdx.x & 3, which = blockIdx.y;     // grid.y = 3 outputs
+    const uint32_t tid = threadIdx.x, p = blockIdx.x / K::CWG, k = blockIdx.x % K::CWG, which = blockIdx.y;     // grid.y = 3 outputs
     const Limb<F> P = limbs[p % L];
     const E *wr = ws + (size_t)p * (7 * N) + (size_t)(4 + which) * N;
     E *out = (which == 0 ? c0 : which == 1 ? c1 : c2) + (size_t)p * N;
     const typename F::TW i2 = load_global(P.itw + 2), i3 = load_global(P.itw + 3);
 #pragma unroll
     for (int m = 0; m < K::CPT; m++) {
-        const uint32_t c = k * (NS / 4) + tid + m * T;
+        const uint32_t c = k * (K::CPT * T) + tid + m * T;
         E v[4];
 #pragma unroll
         for (int q = 0; q < 4; q++) v[q] = wr[q * NS + c];

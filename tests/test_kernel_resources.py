@@ -131,8 +131,13 @@ def test_small_batch_latency_kernel(resources):
                  "ntt_ct4_top_kernel", "ntt_ct4_block_kernel", "ntt_ct4_last_kernel"):                     # ... and the tensor product of few ciphertexts the same way
         for k in _all(kernels, name, 1):
             assert k["spill"] == 0 and k.get("scratch", 0) == 0 and k["vgprs"] <= 256, (name, k)
+    # the block phases run their forward transforms side by side in groups of threads, one LDS image (2^11 x 4 bytes) per group: two groups (multiply), four (tensor product)
+    assert _all(kernels, "ntt_multiply4_block_kernel", 1)[0]["lds"] == 2 * 8192 and _all(kernels, "ntt_ct4_block_kernel", 1)[0]["lds"] == 4 * 8192
     kernels14, _ = resources[("F32", 14)]                        # N = 2^14 would be 1024 threads at 128 VGPRs (the preloaded twiddles spill): not instantiated
     assert not [k for k in kernels14 if "ntt16_" in k]
+    for name in ("ntt_multiply4_block_kernel", "ntt_ct4_block1_kernel"):          # N = 2^14: two groups of 256 threads (multiply), one group (tensor product)
+        for k in _all(kernels14, name, 1):
+            assert k["spill"] == 0 and k.get("scratch", 0) == 0 and k["vgprs"] <= 256, (name, k)
 
 
 def test_compute_bound_kernels_do_not_spill(resources):
