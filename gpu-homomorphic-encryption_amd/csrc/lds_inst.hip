@@ -85,6 +85,18 @@ static bool launch_split_keyswitch(const LdsArgs &A, const Limb<F> *limbs) {
             hipLaunchKernelGGL((ntt_keyswitch2_part_kernel<F, LOGN, true>), pgrid, block, 0, A.stream, part0, part1, (const char *)A.a0, (const E *)A.kb, (const E *)A.ka, limbs, A.L, A.K, A.w);
         else
             hipLaunchKernelGGL((ntt_keyswitch2_part_kernel<F, LOGN, false>), pgrid, block, 0, A.stream, part0, part1, (const char *)A.a0, (const E *)A.kb, (const E *)A.ka, limbs, A.L, A.K, A.w);
+#ifndef FHE_COMB_PAIRED
+        if constexpr (lds_small_multiply(sizeof(E), LOGN)) {      // one workgroup per component on the 16-per-thread inverse (N <= 2^13)
+            const dim3 c16grid(A.polys, 2), c16block(Cfg16<LOGN>::T);
+            if (A.compact_c2)
+                hipLaunchKernelGGL((ntt_keyswitch2_comb16_kernel<F, LOGN, true>), c16grid, c16block, 0, A.stream, (char *)A.r0, (char *)A.r1, (const E *)part0, (const E *)part1,
+                                   (const char *)A.a1, (const char *)A.b0, limbs, A.L, A.K);
+            else
+                hipLaunchKernelGGL((ntt_keyswitch2_comb16_kernel<F, LOGN, false>), c16grid, c16block, 0, A.stream, (char *)A.r0, (char *)A.r1, (const E *)part0, (const E *)part1,
+                                   (const char *)A.r0, (const char *)A.r1, limbs, A.L, A.K);
+            return true;
+        }
+#endif
         if (A.compact_c2)    // fused multiply + relinearise: the addends are the compact c0 (a1) and c1 (b0)
             hipLaunchKernelGGL((ntt_keyswitch2_comb_kernel<F, LOGN, true>), cgrid, block, 0, A.stream, (char *)A.r0, (char *)A.r1, (const E *)part0, (const E *)part1,
                                (const char *)A.a1, (const char *)A.b0, limbs, A.L, A.K);

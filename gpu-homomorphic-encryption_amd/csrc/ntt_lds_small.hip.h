@@ -151,6 +151,13 @@ struct Twiddles16 {
     typename F::TW fa[15], f1[15], f2[15], fz[15], iz[15], i1[15], i2[15], ia[15];     // fa / ia: the uniform pattern-A groups (SGPRs)
     // SUB: the 2^LOGN coefficients are block pre - 2^k of a transform of 2^(LOGN + k) coefficients (twiddles from the big table; the last inverse group
     // is made of ordinary stages, the scaling belongs to the pass over the top stages)
+    // only what inv_core16 (not SUB) reads
+    __device__ __forceinline__ void load_inverse(uint32_t tid, const Limb<F> &P) {
+        if constexpr (C::REM > 1) preload16_uniform<F, LOGN, 2, 4 - C::REM>(ia, P.itw);
+        preload16<F, LOGN, P16Z<LOGN>, 3, 0>(iz, tid, P.itw);
+        preload16<F, LOGN, P16Mid<LOGN, 4>, 3, 0>(i1, tid, P.itw);
+        if constexpr (C::NG == 4) preload16<F, LOGN, P16Mid<LOGN, 8>, 3, 0>(i2, tid, P.itw);
+    }
     template <bool SUB = false>
     __device__ __forceinline__ void load(uint32_t tid, const Limb<F> &P, uint32_t pre = 1) {
         preload16_uniform<F, LOGN, 3, 0>(fa, P.tw, pre);
@@ -725,6 +732,50 @@ ntt_keyswitch2_comb_kernel(char *c0, char *c1, const typename F::E *__restrict__
         for (int r = 0; r < 32; r++) { acc0[r] = F::pw_add(acc0[r], t0[r], P.q, P.q2); acc1[r] = F::pw_add(acc1[r], t1[r], P.q, P.q2); }
     }
     finish_pair<F, LOGN, ADD_COMPACT>(acc0, acc1, t0, t1, lds, tid, P, add0, add1, p, c0, c1);
+}
+
+// The combining launch on the 16-per-thread inverse: one workgroup per (ciphertext, limb, COMPONENT) -- twice the workgroups of ntt_keyswitch2_comb_kernel, each with
+// twice the waves on one inverse transform instead of a paired one (that kernel was the longest launch of the few-ciphertext multiply: 18.9 of 50 us in the trace).
+// The partial accumulators were written in the 32-per-thread register order (slot t + r T32 holds NTT position 32 t + r); this kernel's register r of thread
+// tid is position 16 tid + r.  Sums in the same order (pw_add), same butterflies, same closing arithmetic: bit-identical containers.
+template <class F, int LOGN, bool ADD_COMPACT>
+__global__ void __launch_bounds__(Cfg16<LOGN>::T)
+ntt_keyswitch2_comb16_kernel(char *c0, char *c1, const typename F::E *__restrict__ part0, const typename F::E *__restrict__ part1,
+                             const char *add0, const char *add1, const Limb<F> *__restrict__ limbs, uint32_t L, uint32_t K) {
+    using C = Cfg16<LOGN>;
+    using E = typename F::E;
+    constexpr uint32_t T32 = NttCfg<LOGN>::T;
+    __shared__ E lds[C::N];
+    const uint32_t NP = (L * K + 1) / 2;
+    const uint32_t tid = threadIdx.x, p = blockIdx.x, comp = blockIdx.y;
+    const Limb<F> P = limbs[p % L];
+    const E *part = (comp ? part1 : part0) + (size_t)p * NP * C::N;
+    const char *add = comp ? add1 : add0;
+    Twiddles16<F, LOGN> W;
+    W.load_inverse(tid, P);
+    E acc[16], t[16];
+    const uint32_t s0 = ((tid & 1) * 16) * T32 + (tid >> 1);
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[r] = part[s0 + r * T32];
+    for (uint32_t pr = 1; pr < NP; pr++) {                // the order in which the one-launch kernel accumulates its pairs
+#pragma unroll
+        for (int r = 0; r < 16; r++) t[r] = part[(size_t)pr * C::N + s0 + r * T32];
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[r] = F::pw_add(acc[r], t[r], P.q, P.q2);
+    }
+    if constexpr (ADD_COMPACT) {
+        const E *a = reinterpret_cast<const E *>(add) + (size_t)p * C::N;
+#pragma unroll
+        for (int r = 0; r < 16; r++) t[r] = a[tid + r * C::T];
+    } else {
+        load16<F, LOGN>(add + (size_t)p * (C::N * 32), tid, t);      // in place: the whole addend is in registers before the first store
+    }
+    inv_core16<F, LOGN>(acc, lds, tid, P, W, P.ninv, P.ninv_s, P.ninvw, P.ninvw_s);
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[r] = F::ew_add(F::canon_inv(acc[r], P.q), t[r], P.q);
+    put16<P16A<LOGN>>(lds, tid, acc);                     // the slots this thread read last
+    __syncthreads();
+    store16<F, LOGN>((comp ? c1 : c0) + (size_t)p * (C::N * 32), lds, tid);
 }
 
 }  // namespace fhe_dev

@@ -75,12 +75,15 @@ for B in (1, 4, 16, 64, 256):
         eng.ct_multiply(outs[0], outs[1], outs[2], bufs[0], bufs[1], bufs[2], bufs[3], B)
         eng.relinearize(rk, outs[0], outs[1], outs[2], B)
     e2, r2 = measure(eng, ctrelin)
+    e3, r3 = measure(eng, lambda: eng.ct_multiply_relin(rk, outs[0], outs[1], bufs[0], bufs[1], bufs[2], bufs[3], B))   # FHEContext::multiply as ONE call
     row = {"batch": B, "n": n, "limbs": L, "prime_bits": bits,
+           "ctrelin_one_call": {"eager_us_per_call": e3, "graph_us_per_call": r3, "eager_ct_mul_per_s": B / e3 * 1e6, "graph_ct_mul_per_s": B / r3 * 1e6},
            "multiply": {"eager_us_per_call": e1, "graph_us_per_call": r1, "eager_polymul_per_s": B / e1 * 1e6, "graph_polymul_per_s": B / r1 * 1e6},
            "ctrelin": {"eager_us_per_call": e2, "graph_us_per_call": r2, "eager_ct_mul_per_s": B / e2 * 1e6, "graph_ct_mul_per_s": B / r2 * 1e6,
-                       "launches_per_call": 2}}
+                       "calls": 2}}
     out.append(row)
-    print(f"B={B:4d}  multiply: eager {e1:8.2f} us  graph {r1:8.2f} us   ctrelin (2 launches): eager {e2:8.2f} us  graph {r2:8.2f} us", flush=True)
+    print(f"B={B:4d}  multiply: eager {e1:8.2f} us  graph {r1:8.2f} us   ct_multiply + relinearize (2 calls): eager {e2:8.2f} us  graph {r2:8.2f} us   "
+          f"ct_multiply_relin (1 call): eager {e3:8.2f} us  graph {r3:8.2f} us", flush=True)
 if len(sys.argv) > 1:
     with open(sys.argv[1], "w") as f:
         for r in out:
