@@ -734,7 +734,8 @@ static int split_pairs_workspace(fhe_rns_ntt *h, fhe_dev::LdsArgs &A) {
     if (h->width != FHE_WIDTH_32 || h->single_transforms || !fhe_dev::lds_paired_keyswitch(4, (int)h->log_n)) return FHE_OK;
     const uint32_t NP = (h->L * A.K + 1) / 2;
     if (NP < 2 || A.polys > h->split_pairs_polys) return FHE_OK;
-    int rc = ensure_ws(h, 2 * (size_t)A.polys * NP * h->n * 4); if (rc) return rc;
+    // partial accumulators: one pair per digit PAIR, or (N <= 2^13: the 16-per-thread form, one workgroup per digit) one pair per digit
+    int rc = ensure_ws(h, 2 * (size_t)A.polys * (fhe_dev::lds_small_multiply(4, (int)h->log_n) ? h->L * A.K : NP) * h->n * 4); if (rc) return rc;
     A.pair_ws = h->d_ws;
     return FHE_OK;
 }
@@ -993,7 +994,7 @@ extern "C" int fhe_rns_ntt_reserve(fhe_rns_ntt_t *h, uint32_t batch) {
     }
     // (the few-ciphertext forms are taken by every call of at most split_pairs_polys / coop_polys limb polynomials: a smaller batch than the reserved one included)
     if (lds_class && h->width == FHE_WIDTH_32 && h->split_pairs_polys) {            // few ciphertexts: one workgroup per digit pair, partial sums in the workspace
-        const size_t NP = (LK + 1) / 2, few = polys < h->split_pairs_polys ? polys : h->split_pairs_polys;
+        const size_t NP = fhe_dev::lds_small_multiply(4, (int)h->log_n) ? LK : (LK + 1) / 2, few = polys < h->split_pairs_polys ? polys : h->split_pairs_polys;
         if (2 * few * NP * h->n * 4 > ws) ws = 2 * few * NP * h->n * 4;
     }
     if (h->sub_top) ws3 = 2 * cbytes;                                  // two compact operands of a two-pass multiply

@@ -77,26 +77,32 @@ template <class F, int LOGN>
 static bool launch_split_keyswitch(const LdsArgs &A, const Limb<F> *limbs) {
     using E = typename F::E;
     if constexpr (lds_paired_keyswitch(sizeof(E), LOGN)) {
-        const uint32_t NP = (A.L * A.K + 1) / 2;
-        const dim3 block(NttCfg<LOGN>::T), pgrid(A.polys * NP), cgrid(A.polys);
-        E *part0 = (E *)A.pair_ws, *part1 = part0 + (size_t)A.polys * NP * (1u << LOGN);
         const bool c2_compact = A.compact_c2 || A.c2_only_compact;
-        if (c2_compact)
-            hipLaunchKernelGGL((ntt_keyswitch2_part_kernel<F, LOGN, true>), pgrid, block, 0, A.stream, part0, part1, (const char *)A.a0, (const E *)A.kb, (const E *)A.ka, limbs, A.L, A.K, A.w);
-        else
-            hipLaunchKernelGGL((ntt_keyswitch2_part_kernel<F, LOGN, false>), pgrid, block, 0, A.stream, part0, part1, (const char *)A.a0, (const E *)A.kb, (const E *)A.ka, limbs, A.L, A.K, A.w);
-#ifndef FHE_COMB_PAIRED
-        if constexpr (lds_small_multiply(sizeof(E), LOGN)) {      // one workgroup per component on the 16-per-thread inverse (N <= 2^13)
-            const dim3 c16grid(A.polys, 2), c16block(Cfg16<LOGN>::T);
-            if (A.compact_c2)
-                hipLaunchKernelGGL((ntt_keyswitch2_comb16_kernel<F, LOGN, true>), c16grid, c16block, 0, A.stream, (char *)A.r0, (char *)A.r1, (const E *)part0, (const E *)part1,
-                                   (const char *)A.a1, (const char *)A.b0, limbs, A.L, A.K);
+#ifndef FHE_SPLIT_PAIRED
+        if constexpr (lds_small_multiply(sizeof(E), LOGN)) {      // N <= 2^13: one workgroup per DIGIT and per COMPONENT on the 16-per-thread transforms
+            const uint32_t LK = A.L * A.K;
+            const dim3 b16(Cfg16<LOGN>::T), pgrid(A.polys * LK), cgrid(A.polys, 2);
+            E *part0 = (E *)A.pair_ws, *part1 = part0 + (size_t)A.polys * LK * (1u << LOGN);
+            if (c2_compact)
+                hipLaunchKernelGGL((ntt_keyswitch16_part_kernel<F, LOGN, true>), pgrid, b16, 0, A.stream, part0, part1, (const char *)A.a0, (const E *)A.kb, (const E *)A.ka, limbs, A.L, A.K, A.w);
             else
-                hipLaunchKernelGGL((ntt_keyswitch2_comb16_kernel<F, LOGN, false>), c16grid, c16block, 0, A.stream, (char *)A.r0, (char *)A.r1, (const E *)part0, (const E *)part1,
+                hipLaunchKernelGGL((ntt_keyswitch16_part_kernel<F, LOGN, false>), pgrid, b16, 0, A.stream, part0, part1, (const char *)A.a0, (const E *)A.kb, (const E *)A.ka, limbs, A.L, A.K, A.w);
+            if (A.compact_c2)    // fused multiply + relinearise: the addends are the compact c0 (a1) and c1 (b0)
+                hipLaunchKernelGGL((ntt_keyswitch16_comb_kernel<F, LOGN, true>), cgrid, b16, 0, A.stream, (char *)A.r0, (char *)A.r1, (const E *)part0, (const E *)part1,
+                                   (const char *)A.a1, (const char *)A.b0, limbs, A.L, A.K);
+            else                 // in place on the caller's containers
+                hipLaunchKernelGGL((ntt_keyswitch16_comb_kernel<F, LOGN, false>), cgrid, b16, 0, A.stream, (char *)A.r0, (char *)A.r1, (const E *)part0, (const E *)part1,
                                    (const char *)A.r0, (const char *)A.r1, limbs, A.L, A.K);
             return true;
         }
 #endif
+        const uint32_t NP = (A.L * A.K + 1) / 2;
+        const dim3 block(NttCfg<LOGN>::T), pgrid(A.polys * NP), cgrid(A.polys);
+        E *part0 = (E *)A.pair_ws, *part1 = part0 + (size_t)A.polys * NP * (1u << LOGN);
+        if (c2_compact)
+            hipLaunchKernelGGL((ntt_keyswitch2_part_kernel<F, LOGN, true>), pgrid, block, 0, A.stream, part0, part1, (const char *)A.a0, (const E *)A.kb, (const E *)A.ka, limbs, A.L, A.K, A.w);
+        else
+            hipLaunchKernelGGL((ntt_keyswitch2_part_kernel<F, LOGN, false>), pgrid, block, 0, A.stream, part0, part1, (const char *)A.a0, (const E *)A.kb, (const E *)A.ka, limbs, A.L, A.K, A.w);
         if (A.compact_c2)    // fused multiply + relinearise: the addends are the compact c0 (a1) and c1 (b0)
             hipLaunchKernelGGL((ntt_keyswitch2_comb_kernel<F, LOGN, true>), cgrid, block, 0, A.stream, (char *)A.r0, (char *)A.r1, (const E *)part0, (const E *)part1,
                                (const char *)A.a1, (const char *)A.b0, limbs, A.L, A.K);

@@ -151,6 +151,13 @@ struct Twiddles16 {
     typename F::TW fa[15], f1[15], f2[15], fz[15], iz[15], i1[15], i2[15], ia[15];     // fa / ia: the uniform pattern-A groups (SGPRs)
     // SUB: the 2^LOGN coefficients are block pre - 2^k of a transform of 2^(LOGN + k) coefficients (twiddles from the big table; the last inverse group
     // is made of ordinary stages, the scaling belongs to the pass over the top stages)
+    // only what fwd_core16 reads
+    __device__ __forceinline__ void load_forward(uint32_t tid, const Limb<F> &P) {
+        preload16_uniform<F, LOGN, 3, 0>(fa, P.tw);
+        preload16<F, LOGN, P16Mid<LOGN, LOGN - 8>, 3, 0>(f1, tid, P.tw);
+        if constexpr (C::NG == 4) preload16<F, LOGN, P16Mid<LOGN, LOGN - 12>, 3, 0>(f2, tid, P.tw);
+        preload16<F, LOGN, P16Z<LOGN>, C::REM - 1, 0>(fz, tid, P.tw);
+    }
     // only what inv_core16 (not SUB) reads
     __device__ __forceinline__ void load_inverse(uint32_t tid, const Limb<F> &P) {
         if constexpr (C::REM > 1) preload16_uniform<F, LOGN, 2, 4 - C::REM>(ia, P.itw);
@@ -734,32 +741,75 @@ ntt_keyswitch2_comb_kernel(char *c0, char *c1, const typename F::E *__restrict__
     finish_pair<F, LOGN, ADD_COMPACT>(acc0, acc1, t0, t1, lds, tid, P, add0, add1, p, c0, c1);
 }
 
-// The combining launch on the 16-per-thread inverse: one workgroup per (ciphertext, limb, COMPONENT) -- twice the workgroups of ntt_keyswitch2_comb_kernel, each with
-// twice the waves on one inverse transform instead of a paired one (that kernel was the longest launch of the few-ciphertext multiply: 18.9 of 50 us in the trace).
-// The partial accumulators were written in the 32-per-thread register order (slot t + r T32 holds NTT position 32 t + r); this kernel's register r of thread
-// tid is position 16 tid + r.  Sums in the same order (pw_add), same butterflies, same closing arithmetic: bit-identical containers.
-template <class F, int LOGN, bool ADD_COMPACT>
+// Key switch of few ciphertexts on the 16-per-thread transforms (N <= 2^13, 4-byte residues): the digit-PAIR workgroups above run a paired 32-per-thread
+// transform at one wave per SIMD (11.9 us of the call in the trace, and 18.9 us for the paired combining launch).  Here
+//   * ntt_keyswitch16_part_kernel: one workgroup per (ciphertext, limb, DIGIT): digit extraction, one 16-per-thread forward transform, the two key products of
+//     that digit; the NTT-domain partials go to the workspace in register order (slot tid + r T);
+//   * ntt_keyswitch16_comb_kernel: one workgroup per (ciphertext, limb, COMPONENT): sum of the L K partials, one 16-per-thread inverse transform, addend, store.
+// Twice the workgroups, twice the waves each, single transforms.  Residues are exact, so the order of the (lazy) additions does not show in the canonical
+// result: bit-identical containers.  The key tables are packed for the 32-per-thread kernels (register r of thread t = NTT position 32 t + r, 16-byte chunk c of
+// a row at c T32 16 + t 16): this kernel's register r of thread tid is position 16 tid + r, i.e. chunk 4 (tid & 1) + (r >> 2) of thread tid >> 1.
+template <class F, int LOGN, bool COMPACT>
 __global__ void __launch_bounds__(Cfg16<LOGN>::T)
-ntt_keyswitch2_comb16_kernel(char *c0, char *c1, const typename F::E *__restrict__ part0, const typename F::E *__restrict__ part1,
-                             const char *add0, const char *add1, const Limb<F> *__restrict__ limbs, uint32_t L, uint32_t K) {
+ntt_keyswitch16_part_kernel(typename F::E *__restrict__ part0, typename F::E *__restrict__ part1, const char *__restrict__ c2,
+                            const typename F::E *__restrict__ kb, const typename F::E *__restrict__ ka,
+                            const Limb<F> *__restrict__ limbs, uint32_t L, uint32_t K, uint32_t w) {
     using C = Cfg16<LOGN>;
     using E = typename F::E;
+    static_assert(sizeof(E) == 4, "packed key rows of the 4-byte residues");
+    typedef E VecE __attribute__((ext_vector_type(4)));
     constexpr uint32_t T32 = NttCfg<LOGN>::T;
     __shared__ E lds[C::N];
-    const uint32_t NP = (L * K + 1) / 2;
+    const uint32_t LK = L * K;
+    const uint32_t tid = threadIdx.x, g = blockIdx.x % LK, p = blockIdx.x / LK, b = p / L, i = p % L, j = g / K, k = g % K;
+    const Limb<F> P = limbs[i];
+    Twiddles16<F, LOGN> W;
+    W.load_forward(tid, P);
+    E x[16];
+    if constexpr (COMPACT) {
+        const E *src = reinterpret_cast<const E *>(c2) + ((size_t)b * L + j) * C::N;
+#pragma unroll
+        for (int r = 0; r < 16; r++) x[r] = src[tid + r * C::T];
+    } else {
+        load16<F, LOGN>(c2 + ((size_t)b * L + j) * (C::N * 32), tid, x);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; r++) x[r] = F::digit(x[r], k * w, w);
+    fwd_core16<F, LOGN>(x, lds, tid, P, W);
+    const TableBuf KB(kb), KA(ka);
+    const uint32_t voff = ((tid & 1) * 4 * T32 + (tid >> 1)) * 16, row = (uint32_t)((((size_t)g * L + i) * C::N) * sizeof(E));
+    E *o0 = part0 + ((size_t)p * LK + g) * C::N, *o1 = part1 + ((size_t)p * LK + g) * C::N;
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const VecE vb = KB.template load16<VecE>(voff, row + c * T32 * 16), va = KA.template load16<VecE>(voff, row + c * T32 * 16);
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const int r = 4 * c + e;
+            o0[tid + r * C::T] = F::pw_mul(vb[e], x[r], P.q, P.qinv);
+            o1[tid + r * C::T] = F::pw_mul(va[e], x[r], P.q, P.qinv);
+        }
+    }
+}
+template <class F, int LOGN, bool ADD_COMPACT>
+__global__ void __launch_bounds__(Cfg16<LOGN>::T)
+ntt_keyswitch16_comb_kernel(char *c0, char *c1, const typename F::E *__restrict__ part0, const typename F::E *__restrict__ part1,
+                            const char *add0, const char *add1, const Limb<F> *__restrict__ limbs, uint32_t L, uint32_t K) {
+    using C = Cfg16<LOGN>;
+    using E = typename F::E;
+    __shared__ E lds[C::N];
+    const uint32_t LK = L * K;
     const uint32_t tid = threadIdx.x, p = blockIdx.x, comp = blockIdx.y;
     const Limb<F> P = limbs[p % L];
-    const E *part = (comp ? part1 : part0) + (size_t)p * NP * C::N;
+    const E *part = (comp ? part1 : part0) + (size_t)p * LK * C::N;
     const char *add = comp ? add1 : add0;
     Twiddles16<F, LOGN> W;
     W.load_inverse(tid, P);
     E acc[16], t[16];
-    const uint32_t s0 = ((tid & 1) * 16) * T32 + (tid >> 1);
 #pragma unroll
-    for (int r = 0; r < 16; r++) acc[r] = part[s0 + r * T32];
-    for (uint32_t pr = 1; pr < NP; pr++) {                // the order in which the one-launch kernel accumulates its pairs
+    for (int r = 0; r < 16; r++) acc[r] = part[tid + r * C::T];
+    for (uint32_t g = 1; g < LK; g++) {
 #pragma unroll
-        for (int r = 0; r < 16; r++) t[r] = part[(size_t)pr * C::N + s0 + r * T32];
+        for (int r = 0; r < 16; r++) t[r] = part[(size_t)g * C::N + tid + r * C::T];
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[r] = F::pw_add(acc[r], t[r], P.q, P.q2);
     }

@@ -124,8 +124,9 @@ def test_small_batch_latency_kernel(resources):
         assert k["spill"] == 0 and k.get("scratch", 0) == 0 and k["vgprs"] <= 256 and k["occupancy"] >= 2 and k["lds"] == 32768, k
     for k in _all(kernels, "ntt16_ct_multiply_kernel", 1):       # the tensor product of few ciphertexts: four 16-entry arrays + 90 twiddles
         assert k["spill"] == 0 and k.get("scratch", 0) == 0 and k["vgprs"] <= 256 and k["occupancy"] >= 2 and k["lds"] == 32768, k
-    for k in _all(kernels, "ntt_keyswitch2_comb16_kernel", 2):                  # ... whose combining launch runs one 16-per-thread inverse per component
-        assert k["spill"] == 0 and k.get("scratch", 0) == 0 and k["vgprs"] <= 256 and k["lds"] == 32768, k
+    for name in ("ntt_keyswitch16_part_kernel", "ntt_keyswitch16_comb_kernel"):  # N <= 2^13: one workgroup per digit / per component on the 16-per-thread transforms
+        for k in _all(kernels, name, 2):
+            assert k["spill"] == 0 and k.get("scratch", 0) == 0 and k["vgprs"] <= 256 and k["lds"] == 32768, (name, k)
     for name in ("ntt_keyswitch2_part_kernel", "ntt_keyswitch2_comb_kernel"):   # key switch of few ciphertexts: one workgroup per digit pair + combine
         for k in _all(kernels, name, 2):
             assert k["spill"] == 0 and k.get("scratch", 0) == 0 and k["vgprs"] <= 256 and k["occupancy"] >= 2 and k["lds"] == 2 * 33792, (name, k)
