@@ -994,7 +994,8 @@ extern "C" int fhe_rns_ntt_reserve(fhe_rns_ntt_t *h, uint32_t batch) {
     }
     // (the few-ciphertext forms are taken by every call of at most split_pairs_polys / coop_polys limb polynomials: a smaller batch than the reserved one included)
     if (lds_class && h->width == FHE_WIDTH_32 && h->split_pairs_polys) {            // few ciphertexts: one workgroup per digit pair, partial sums in the workspace
-        const size_t NP = fhe_dev::lds_small_multiply(4, (int)h->log_n) ? LK : (LK + 1) / 2, few = polys < h->split_pairs_polys ? polys : h->split_pairs_polys;
+        // N <= 2^13: one pair per digit, and two digit sources in a blind-rotation step (2 L K partials per limb polynomial)
+        const size_t NP = fhe_dev::lds_small_multiply(4, (int)h->log_n) ? 2 * LK : (LK + 1) / 2, few = polys < h->split_pairs_polys ? polys : h->split_pairs_polys;
         if (2 * few * NP * h->n * 4 > ws) ws = 2 * few * NP * h->n * 4;
     }
     if (h->sub_top) ws3 = 2 * cbytes;                                  // two compact operands of a two-pass multiply
@@ -1673,12 +1674,13 @@ static int blind_rotate_step_general(fhe_rns_ntt_t *h, const fhe_relin_keys_t *r
 // One step as ONE launch (word-sized classes with packed rows): (out0, out1) = (in0, in1) + ExtProd((X^a - 1) * in, RGSW).
 static int blind_rotate_step_fused(fhe_rns_ntt_t *h, const fhe_relin_keys_t *r0, const fhe_relin_keys_t *r1, void *out0, void *out1, const void *in0,
                                    const void *in1, const uint32_t *d_shifts, uint32_t batch, bool in_compact = false, bool out_compact = false,
-                                   const void *rot0 = nullptr, const void *rot1 = nullptr) {
+                                   const void *rot0 = nullptr, const void *rot1 = nullptr, void *pair_ws = nullptr) {
     fhe_dev::lds_launch_fn fn = fhe_dev::lds_lookup(lds_width_id(h), (int)h->log_n);
     if (!fn) return fail(FHE_ERR_UNSUPPORTED, "transform size outside the LDS-resident range");
     fhe_dev::LdsArgs A{fhe_dev::LDS_EXTPROD, out0, out1, nullptr, in0, in1, rot0, rot1, h->d_limbs, h->L, batch * h->L, h->stream};   // b0, b1: pre-rotated digit sources (three-array kernel)
     A.kb = r0->d_pkb; A.ka = r0->d_pka; A.kb1 = r1->d_pkb; A.ka1 = r1->d_pka; A.K = r0->K; A.w = r0->decomp_bits; A.shifts = d_shifts;
     A.in_compact = in_compact; A.out_compact = out_compact;
+    A.pair_ws = pair_ws;                 // few accumulators: partial accumulators of the one-workgroup-per-digit form
     A.joint3 = use_joint3(h, true, false);
     A.global_twiddles = h->global_twiddles;
     A.single_transforms = h->single_transforms;
@@ -1709,6 +1711,33 @@ extern "C" int fhe_blind_rotate(fhe_rns_ntt_t *h, const fhe_relin_keys_t *const 
     if (!fused) {
         for (uint32_t s = 0; s < steps; s++)
             if ((rc = blind_rotate_step_general(h, rows_c0[s], rows_c1[s], d_acc0, d_acc1, d_shifts + (size_t)s * batch, d_tmp0, d_tmp1, batch))) return rc;
+        return FHE_OK;
+    }
+    // Few accumulators (4-byte residues, N <= 2^13; what a bootstrapping of one or a few ciphertexts looks like): with one workgroup per (accumulator, limb)
+    // a step lasts as long as that workgroup's 2 L K / 2 paired transforms back to back (103 us per external product at N = 8192, L = 4, w = 16, batch 1).
+    // Here a step is three launches: the monomial factor (X^a - 1) once per step (a streaming pass), one workgroup per (accumulator, limb, component, DIGIT) on the
+    // 16-per-thread forward transform with that digit's two key products, and one workgroup per (accumulator, limb, output component) that sums the 2 L K partials,
+    // runs one inverse transform and adds the accumulator (ntt_keyswitch16_{part,comb}_kernel).  The pair stays compact between the steps.
+    if (steps >= 1 && h->width == FHE_WIDTH_32 && !h->single_transforms && !h->no_compact_blind_rotate && !h->no_prerotation && fhe_dev::lds_small_multiply(4, (int)h->log_n) &&
+        h->split_pairs_polys && batch * h->L <= h->split_pairs_polys) {
+        const size_t cbytes = (size_t)batch * h->L * h->n * 4, count = (size_t)batch * h->L * h->n;
+        if ((rc = ensure_ws2(h, 6 * cbytes))) return rc;
+        char *w0 = (char *)h->d_ws2;
+        char *pp[2][2] = {{w0, w0 + cbytes}, {w0 + 2 * cbytes, w0 + 3 * cbytes}};
+        char *rot0 = w0 + 4 * cbytes, *rot1 = w0 + 5 * cbytes;       // (X^a - 1) * acc of the current step
+        uint32_t kmax = 0;
+        for (uint32_t s = 0; s < steps; s++) kmax = rows_c0[s]->K > kmax ? rows_c0[s]->K : kmax;
+        if ((rc = ensure_ws(h, 2 * count * (2 * (size_t)h->L * kmax) * 4))) return rc;      // two partial accumulators per (limb polynomial, component, digit)
+        if ((rc = compact_poly(h, pp[1][0], d_acc0, count))) return rc;
+        if ((rc = compact_poly(h, pp[1][1], d_acc1, count))) return rc;
+        for (uint32_t s = 0; s < steps; s++) {
+            const bool last = s + 1 == steps;
+            const void *i0 = pp[(s + 1) & 1][0], *i1 = pp[(s + 1) & 1][1];
+            void *o0 = last ? d_acc0 : pp[s & 1][0], *o1 = last ? d_acc1 : pp[s & 1][1];
+            const uint32_t *sh = d_shifts + (size_t)s * batch;
+            if ((rc = monomial_compact(h, rot0, i0, sh, count)) || (rc = monomial_compact(h, rot1, i1, sh, count))) return rc;
+            if ((rc = blind_rotate_step_fused(h, rows_c0[s], rows_c1[s], o0, o1, i0, i1, sh, batch, true, !last, rot0, rot1, h->d_ws))) return rc;
+        }
         return FHE_OK;
     }
     // Paired kernel (4-byte residues up to N = 2^14): the accumulator pair lives in COMPACT form for the whole call (workspace ping-pong, 4

@@ -84,15 +84,17 @@ static bool launch_split_keyswitch(const LdsArgs &A, const Limb<F> *limbs) {
             const dim3 b16(Cfg16<LOGN>::T), pgrid(A.polys * LK), cgrid(A.polys, 2);
             E *part0 = (E *)A.pair_ws, *part1 = part0 + (size_t)A.polys * LK * (1u << LOGN);
             if (c2_compact)
-                hipLaunchKernelGGL((ntt_keyswitch16_part_kernel<F, LOGN, true>), pgrid, b16, 0, A.stream, part0, part1, (const char *)A.a0, (const E *)A.kb, (const E *)A.ka, limbs, A.L, A.K, A.w);
+                hipLaunchKernelGGL((ntt_keyswitch16_part_kernel<F, LOGN, true>), pgrid, b16, 0, A.stream, part0, part1, (const char *)A.a0, (const char *)nullptr, (const E *)A.kb, (const E *)A.ka,
+                                   (const E *)nullptr, (const E *)nullptr, limbs, A.L, A.K, A.w);
             else
-                hipLaunchKernelGGL((ntt_keyswitch16_part_kernel<F, LOGN, false>), pgrid, b16, 0, A.stream, part0, part1, (const char *)A.a0, (const E *)A.kb, (const E *)A.ka, limbs, A.L, A.K, A.w);
+                hipLaunchKernelGGL((ntt_keyswitch16_part_kernel<F, LOGN, false>), pgrid, b16, 0, A.stream, part0, part1, (const char *)A.a0, (const char *)nullptr, (const E *)A.kb, (const E *)A.ka,
+                                   (const E *)nullptr, (const E *)nullptr, limbs, A.L, A.K, A.w);
             if (A.compact_c2)    // fused multiply + relinearise: the addends are the compact c0 (a1) and c1 (b0)
                 hipLaunchKernelGGL((ntt_keyswitch16_comb_kernel<F, LOGN, true>), cgrid, b16, 0, A.stream, (char *)A.r0, (char *)A.r1, (const E *)part0, (const E *)part1,
-                                   (const char *)A.a1, (const char *)A.b0, limbs, A.L, A.K);
+                                   (const char *)A.a1, (const char *)A.b0, limbs, A.L, LK);
             else                 // in place on the caller's containers
                 hipLaunchKernelGGL((ntt_keyswitch16_comb_kernel<F, LOGN, false>), cgrid, b16, 0, A.stream, (char *)A.r0, (char *)A.r1, (const E *)part0, (const E *)part1,
-                                   (const char *)A.r0, (const char *)A.r1, limbs, A.L, A.K);
+                                   (const char *)A.r0, (const char *)A.r1, limbs, A.L, LK);
             return true;
         }
 #endif
@@ -109,6 +111,29 @@ static bool launch_split_keyswitch(const LdsArgs &A, const Limb<F> *limbs) {
         else                 // in place on the caller's containers
             hipLaunchKernelGGL((ntt_keyswitch2_comb_kernel<F, LOGN, false>), cgrid, block, 0, A.stream, (char *)A.r0, (char *)A.r1, (const E *)part0, (const E *)part1,
                                (const char *)A.r0, (const char *)A.r1, limbs, A.L, A.K);
+        return true;
+    } else {
+        return false;
+    }
+}
+
+// external product of a blind-rotation step for few accumulators (N <= 2^13, 4-byte residues): the key-switch launches above with two digit sources -- the
+// pre-rotated components b0, b1 (compact) with their RGSW rows -- and the accumulator pair a0, a1 (compact) as addends; r0, r1 compact or containers
+template <class F, int LOGN>
+static bool launch_split_extprod(const LdsArgs &A, const Limb<F> *limbs) {
+    using E = typename F::E;
+    if constexpr (lds_small_multiply(sizeof(E), LOGN)) {
+        const uint32_t LK = A.L * A.K;
+        const dim3 b16(Cfg16<LOGN>::T), pgrid(A.polys * LK, 2), cgrid(A.polys, 2);
+        E *part0 = (E *)A.pair_ws, *part1 = part0 + (size_t)A.polys * 2 * LK * (1u << LOGN);
+        hipLaunchKernelGGL((ntt_keyswitch16_part_kernel<F, LOGN, true>), pgrid, b16, 0, A.stream, part0, part1, (const char *)A.b0, (const char *)A.b1, (const E *)A.kb, (const E *)A.ka,
+                           (const E *)A.kb1, (const E *)A.ka1, limbs, A.L, A.K, A.w);
+        if (A.out_compact)
+            hipLaunchKernelGGL((ntt_keyswitch16_comb_kernel<F, LOGN, true, true>), cgrid, b16, 0, A.stream, (char *)A.r0, (char *)A.r1, (const E *)part0, (const E *)part1,
+                               (const char *)A.a0, (const char *)A.a1, limbs, A.L, 2 * LK);
+        else
+            hipLaunchKernelGGL((ntt_keyswitch16_comb_kernel<F, LOGN, true, false>), cgrid, b16, 0, A.stream, (char *)A.r0, (char *)A.r1, (const E *)part0, (const E *)part1,
+                               (const char *)A.a0, (const char *)A.a1, limbs, A.L, 2 * LK);
         return true;
     } else {
         return false;
@@ -264,6 +289,7 @@ void CAT(lds_launch_, FHE_FIELD, FHE_LOGN)(const LdsArgs &A) {
         }
         case LDS_EXTPROD: {
             using E = typename F::E;
+            if (A.pair_ws && A.b0 && A.in_compact && launch_split_extprod<F, LOGN>(A, limbs)) break;      // few accumulators: one workgroup per digit / per component
             if constexpr (lds_keyswitch_split(sizeof(E), LOGN)) {
                 if (A.joint3) {
                     if constexpr (lds_keyswitch_joint3(sizeof(E), LOGN)) {

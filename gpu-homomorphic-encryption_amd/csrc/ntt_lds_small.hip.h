@@ -749,10 +749,13 @@ ntt_keyswitch2_comb_kernel(char *c0, char *c1, const typename F::E *__restrict__
 // Twice the workgroups, twice the waves each, single transforms.  Residues are exact, so the order of the (lazy) additions does not show in the canonical
 // result: bit-identical containers.  The key tables are packed for the 32-per-thread kernels (register r of thread t = NTT position 32 t + r, 16-byte chunk c of
 // a row at c T32 16 + t 16): this kernel's register r of thread tid is position 16 tid + r, i.e. chunk 4 (tid & 1) + (r >> 2) of thread tid >> 1.
+// The external product of a blind-rotation step for few accumulators is the same two launches with TWO digit sources (grid.y = 2: the pre-rotated components
+// (X^a - 1) acc_0 and (X^a - 1) acc_1, each with its own RGSW rows) and 2 L K partials per limb polynomial; the combining launch then adds the accumulator itself.
 template <class F, int LOGN, bool COMPACT>
 __global__ void __launch_bounds__(Cfg16<LOGN>::T)
-ntt_keyswitch16_part_kernel(typename F::E *__restrict__ part0, typename F::E *__restrict__ part1, const char *__restrict__ c2,
+ntt_keyswitch16_part_kernel(typename F::E *__restrict__ part0, typename F::E *__restrict__ part1, const char *__restrict__ c2, const char *__restrict__ c2b,
                             const typename F::E *__restrict__ kb, const typename F::E *__restrict__ ka,
+                            const typename F::E *__restrict__ kb_b, const typename F::E *__restrict__ ka_b,
                             const Limb<F> *__restrict__ limbs, uint32_t L, uint32_t K, uint32_t w) {
     using C = Cfg16<LOGN>;
     using E = typename F::E;
@@ -760,9 +763,10 @@ ntt_keyswitch16_part_kernel(typename F::E *__restrict__ part0, typename F::E *__
     typedef E VecE __attribute__((ext_vector_type(4)));
     constexpr uint32_t T32 = NttCfg<LOGN>::T;
     __shared__ E lds[C::N];
-    const uint32_t LK = L * K;
+    const uint32_t LK = L * K, comp = blockIdx.y, NPART = LK * gridDim.y;
     const uint32_t tid = threadIdx.x, g = blockIdx.x % LK, p = blockIdx.x / LK, b = p / L, i = p % L, j = g / K, k = g % K;
     const Limb<F> P = limbs[i];
+    if (comp) { c2 = c2b; kb = kb_b; ka = ka_b; }
     Twiddles16<F, LOGN> W;
     W.load_forward(tid, P);
     E x[16];
@@ -778,7 +782,8 @@ ntt_keyswitch16_part_kernel(typename F::E *__restrict__ part0, typename F::E *__
     fwd_core16<F, LOGN>(x, lds, tid, P, W);
     const TableBuf KB(kb), KA(ka);
     const uint32_t voff = ((tid & 1) * 4 * T32 + (tid >> 1)) * 16, row = (uint32_t)((((size_t)g * L + i) * C::N) * sizeof(E));
-    E *o0 = part0 + ((size_t)p * LK + g) * C::N, *o1 = part1 + ((size_t)p * LK + g) * C::N;
+    const size_t slot = ((size_t)p * NPART + comp * LK + g) * C::N;
+    E *o0 = part0 + slot, *o1 = part1 + slot;
 #pragma unroll
     for (int c = 0; c < 4; c++) {
         const VecE vb = KB.template load16<VecE>(voff, row + c * T32 * 16), va = KA.template load16<VecE>(voff, row + c * T32 * 16);
@@ -790,14 +795,13 @@ ntt_keyswitch16_part_kernel(typename F::E *__restrict__ part0, typename F::E *__
         }
     }
 }
-template <class F, int LOGN, bool ADD_COMPACT>
+template <class F, int LOGN, bool ADD_COMPACT, bool OUT_COMPACT = false>
 __global__ void __launch_bounds__(Cfg16<LOGN>::T)
 ntt_keyswitch16_comb_kernel(char *c0, char *c1, const typename F::E *__restrict__ part0, const typename F::E *__restrict__ part1,
-                            const char *add0, const char *add1, const Limb<F> *__restrict__ limbs, uint32_t L, uint32_t K) {
+                            const char *add0, const char *add1, const Limb<F> *__restrict__ limbs, uint32_t L, uint32_t LK) {   // LK = partials per limb polynomial
     using C = Cfg16<LOGN>;
     using E = typename F::E;
     __shared__ E lds[C::N];
-    const uint32_t LK = L * K;
     const uint32_t tid = threadIdx.x, p = blockIdx.x, comp = blockIdx.y;
     const Limb<F> P = limbs[p % L];
     const E *part = (comp ? part1 : part0) + (size_t)p * LK * C::N;
@@ -823,9 +827,15 @@ ntt_keyswitch16_comb_kernel(char *c0, char *c1, const typename F::E *__restrict_
     inv_core16<F, LOGN>(acc, lds, tid, P, W, P.ninv, P.ninv_s, P.ninvw, P.ninvw_s);
 #pragma unroll
     for (int r = 0; r < 16; r++) acc[r] = F::ew_add(F::canon_inv(acc[r], P.q), t[r], P.q);
-    put16<P16A<LOGN>>(lds, tid, acc);                     // the slots this thread read last
-    __syncthreads();
-    store16<F, LOGN>((comp ? c1 : c0) + (size_t)p * (C::N * 32), lds, tid);
+    if constexpr (OUT_COMPACT) {                          // the accumulator of a blind-rotation loop stays compact between steps
+        E *o = reinterpret_cast<E *>(comp ? c1 : c0) + (size_t)p * C::N;
+#pragma unroll
+        for (int r = 0; r < 16; r++) o[tid + r * C::T] = acc[r];
+    } else {
+        put16<P16A<LOGN>>(lds, tid, acc);                 // the slots this thread read last
+        __syncthreads();
+        store16<F, LOGN>((comp ? c1 : c0) + (size_t)p * (C::N * 32), lds, tid);
+    }
 }
 
 }  // namespace fhe_dev

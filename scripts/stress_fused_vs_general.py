@@ -38,7 +38,7 @@ while time.time() - t0 < budget:
     engs = {"fused": make(), "general": make(FHE_HIP_NO_FUSED_KEYSWITCH="1", FHE_HIP_NO_FUSED_BLIND_ROTATE="1"),
             "fused-single": make(FHE_HIP_NO_PAIRED_TRANSFORMS="1"),
             "fused-alt": make(FHE_HIP_NO_TWO_LAUNCH_CT="1", FHE_HIP_SPLIT_KEYSWITCH="1"),   # the other forms of the N = 2^14 / 2^15 kernels
-            # the round-2 forms of what round 3 changed: c2 / accumulators as containers, monomial factor per digit, one stream, throughput kernels for few ciphertexts
+            # the round-2 forms of what round 3 changed: c2 / accumulators as containers, monomial factor per digit, one stream, throughput kernels for few ciphertexts / accumulators
             "fused-r2": make(FHE_HIP_NO_C2_COMPACTION="1", FHE_HIP_NO_PREROTATION="1", FHE_HIP_CT_RELIN_CHUNKS="1", FHE_HIP_SPLIT_PAIRS_POLYS="0", FHE_HIP_COOP_POLYS="0",
                              **({"FHE_HIP_NO_COMPACT_BLIND_ROTATE": "1"} if cases % 2 else {}))}
     K = engs["fused"].relin_num_digits(w)

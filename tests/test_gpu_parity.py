@@ -814,7 +814,7 @@ def test_blind_rotate_step_matches_oracle(eng, oracle, n, spec, w, batch):
                                                   (32768, ("bits", 30, 2), 16, 2, 2), (4096, ("bits", 40, 2), 20, 3, 3), (2048, ("bits", 60, 2), 32, 2, 2),
                                                   (256, ("bits", 250, 1), 64, 2, 2), (2048, ("bits", 64, 2), 32, 2, 3),
                                                   (16384, ("bits", 40, 2), 20, 2, 2), (16384, ("bits", 60, 1), 32, 1, 3)])      # three-array / split kernels
-@pytest.mark.parametrize("fused", [True, False, "single", "containers", "split", "no-prerotation"])
+@pytest.mark.parametrize("fused", [True, False, "single", "containers", "split", "no-prerotation", "one-workgroup-per-limb"])
 def test_blind_rotate_loop_matches_oracle(eng, oracle, monkeypatch, n, spec, w, batch, steps, fused):
     """fhe_blind_rotate: `steps` external products with a different RGSW row set and different shifts per step; the fused
     one-launch-per-step path (ping-pong buffers, odd and even step counts; digit transforms two at a time -- the default where
@@ -829,6 +829,8 @@ def test_blind_rotate_loop_matches_oracle(eng, oracle, monkeypatch, n, spec, w, 
         monkeypatch.setenv("FHE_HIP_NO_COMPACT_BLIND_ROTATE", "1")
     elif fused == "no-prerotation":  # three-array kernels: the monomial factor applied per digit inside the kernel instead of once per step by monomial_compact_kernel
         monkeypatch.setenv("FHE_HIP_NO_PREROTATION", "1")
+    elif fused == "one-workgroup-per-limb":   # 4-byte residues, N <= 2^13, few accumulators: the default is one workgroup per digit + one per component (three launches
+        monkeypatch.setenv("FHE_HIP_SPLIT_PAIRS_POLYS", "0")   # per step); this keeps the paired one-launch kernel these shapes ran before
     moduli = _moduli(spec, n); L = len(moduli)
     e = eng.RnsNttEngine(n, moduli); rp = oracle.RnsPlan(n, moduli)
     K = e.relin_num_digits(w)
