@@ -995,7 +995,7 @@ extern "C" int fhe_rns_ntt_reserve(fhe_rns_ntt_t *h, uint32_t batch) {
     // (the few-ciphertext forms are taken by every call of at most split_pairs_polys / coop_polys limb polynomials: a smaller batch than the reserved one included)
     if (lds_class && h->width == FHE_WIDTH_32 && h->split_pairs_polys) {            // few ciphertexts: one workgroup per digit pair, partial sums in the workspace
         // N <= 2^13: one pair per digit, and two digit sources in a blind-rotation step (2 L K partials per limb polynomial)
-        const size_t NP = fhe_dev::lds_small_multiply(4, (int)h->log_n) ? 2 * LK : (LK + 1) / 2, few = polys < h->split_pairs_polys ? polys : h->split_pairs_polys;
+        const size_t NP = fhe_dev::lds_small_multiply(4, (int)h->log_n) ? 2 * LK : 2 * ((LK + 1) / 2), few = polys < h->split_pairs_polys ? polys : h->split_pairs_polys;
         if (2 * few * NP * h->n * 4 > ws) ws = 2 * few * NP * h->n * 4;
     }
     if (h->sub_top) ws3 = 2 * cbytes;                                  // two compact operands of a two-pass multiply
@@ -1718,7 +1718,8 @@ extern "C" int fhe_blind_rotate(fhe_rns_ntt_t *h, const fhe_relin_keys_t *const 
     // Here a step is three launches: the monomial factor (X^a - 1) once per step (a streaming pass), one workgroup per (accumulator, limb, component, DIGIT) on the
     // 16-per-thread forward transform with that digit's two key products, and one workgroup per (accumulator, limb, output component) that sums the 2 L K partials,
     // runs one inverse transform and adds the accumulator (ntt_keyswitch16_{part,comb}_kernel).  The pair stays compact between the steps.
-    if (steps >= 1 && h->width == FHE_WIDTH_32 && !h->single_transforms && !h->no_compact_blind_rotate && !h->no_prerotation && fhe_dev::lds_small_multiply(4, (int)h->log_n) &&
+    // (N = 2^14: the same three launches on the paired 32-per-thread transforms, one workgroup per digit PAIR of a component)
+    if (steps >= 1 && h->width == FHE_WIDTH_32 && !h->single_transforms && !h->no_compact_blind_rotate && !h->no_prerotation && fhe_dev::lds_paired_keyswitch(4, (int)h->log_n) &&
         h->split_pairs_polys && batch * h->L <= h->split_pairs_polys) {
         const size_t cbytes = (size_t)batch * h->L * h->n * 4, count = (size_t)batch * h->L * h->n;
         if ((rc = ensure_ws2(h, 6 * cbytes))) return rc;
@@ -1727,7 +1728,8 @@ extern "C" int fhe_blind_rotate(fhe_rns_ntt_t *h, const fhe_relin_keys_t *const 
         char *rot0 = w0 + 4 * cbytes, *rot1 = w0 + 5 * cbytes;       // (X^a - 1) * acc of the current step
         uint32_t kmax = 0;
         for (uint32_t s = 0; s < steps; s++) kmax = rows_c0[s]->K > kmax ? rows_c0[s]->K : kmax;
-        if ((rc = ensure_ws(h, 2 * count * (2 * (size_t)h->L * kmax) * 4))) return rc;      // two partial accumulators per (limb polynomial, component, digit)
+        const size_t parts = fhe_dev::lds_small_multiply(4, (int)h->log_n) ? 2 * (size_t)h->L * kmax : 2 * (((size_t)h->L * kmax + 1) / 2);
+        if ((rc = ensure_ws(h, 2 * count * parts * 4))) return rc;      // two partial accumulators per (limb polynomial, component, digit or digit pair)
         if ((rc = compact_poly(h, pp[1][0], d_acc0, count))) return rc;
         if ((rc = compact_poly(h, pp[1][1], d_acc1, count))) return rc;
         for (uint32_t s = 0; s < steps; s++) {

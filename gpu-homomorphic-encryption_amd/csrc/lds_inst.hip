@@ -102,15 +102,17 @@ static bool launch_split_keyswitch(const LdsArgs &A, const Limb<F> *limbs) {
         const dim3 block(NttCfg<LOGN>::T), pgrid(A.polys * NP), cgrid(A.polys);
         E *part0 = (E *)A.pair_ws, *part1 = part0 + (size_t)A.polys * NP * (1u << LOGN);
         if (c2_compact)
-            hipLaunchKernelGGL((ntt_keyswitch2_part_kernel<F, LOGN, true>), pgrid, block, 0, A.stream, part0, part1, (const char *)A.a0, (const E *)A.kb, (const E *)A.ka, limbs, A.L, A.K, A.w);
+            hipLaunchKernelGGL((ntt_keyswitch2_part_kernel<F, LOGN, true>), pgrid, block, 0, A.stream, part0, part1, (const char *)A.a0, (const char *)nullptr, (const E *)A.kb, (const E *)A.ka,
+                               (const E *)nullptr, (const E *)nullptr, limbs, A.L, A.K, A.w);
         else
-            hipLaunchKernelGGL((ntt_keyswitch2_part_kernel<F, LOGN, false>), pgrid, block, 0, A.stream, part0, part1, (const char *)A.a0, (const E *)A.kb, (const E *)A.ka, limbs, A.L, A.K, A.w);
+            hipLaunchKernelGGL((ntt_keyswitch2_part_kernel<F, LOGN, false>), pgrid, block, 0, A.stream, part0, part1, (const char *)A.a0, (const char *)nullptr, (const E *)A.kb, (const E *)A.ka,
+                               (const E *)nullptr, (const E *)nullptr, limbs, A.L, A.K, A.w);
         if (A.compact_c2)    // fused multiply + relinearise: the addends are the compact c0 (a1) and c1 (b0)
             hipLaunchKernelGGL((ntt_keyswitch2_comb_kernel<F, LOGN, true>), cgrid, block, 0, A.stream, (char *)A.r0, (char *)A.r1, (const E *)part0, (const E *)part1,
-                               (const char *)A.a1, (const char *)A.b0, limbs, A.L, A.K);
+                               (const char *)A.a1, (const char *)A.b0, limbs, A.L, NP);
         else                 // in place on the caller's containers
             hipLaunchKernelGGL((ntt_keyswitch2_comb_kernel<F, LOGN, false>), cgrid, block, 0, A.stream, (char *)A.r0, (char *)A.r1, (const E *)part0, (const E *)part1,
-                               (const char *)A.r0, (const char *)A.r1, limbs, A.L, A.K);
+                               (const char *)A.r0, (const char *)A.r1, limbs, A.L, NP);
         return true;
     } else {
         return false;
@@ -134,6 +136,19 @@ static bool launch_split_extprod(const LdsArgs &A, const Limb<F> *limbs) {
         else
             hipLaunchKernelGGL((ntt_keyswitch16_comb_kernel<F, LOGN, true, false>), cgrid, b16, 0, A.stream, (char *)A.r0, (char *)A.r1, (const E *)part0, (const E *)part1,
                                (const char *)A.a0, (const char *)A.a1, limbs, A.L, 2 * LK);
+        return true;
+    } else if constexpr (lds_paired_keyswitch(sizeof(E), LOGN)) {      // N = 2^14: one workgroup per digit PAIR of a component (paired 32-per-thread transform), paired combining launch
+        const uint32_t NP = (A.L * A.K + 1) / 2;
+        const dim3 block(NttCfg<LOGN>::T), pgrid(A.polys * NP, 2), cgrid(A.polys);
+        E *part0 = (E *)A.pair_ws, *part1 = part0 + (size_t)A.polys * 2 * NP * (1u << LOGN);
+        hipLaunchKernelGGL((ntt_keyswitch2_part_kernel<F, LOGN, true>), pgrid, block, 0, A.stream, part0, part1, (const char *)A.b0, (const char *)A.b1, (const E *)A.kb, (const E *)A.ka,
+                           (const E *)A.kb1, (const E *)A.ka1, limbs, A.L, A.K, A.w);
+        if (A.out_compact)
+            hipLaunchKernelGGL((ntt_keyswitch2_comb_kernel<F, LOGN, true, true>), cgrid, block, 0, A.stream, (char *)A.r0, (char *)A.r1, (const E *)part0, (const E *)part1,
+                               (const char *)A.a0, (const char *)A.a1, limbs, A.L, 2 * NP);
+        else
+            hipLaunchKernelGGL((ntt_keyswitch2_comb_kernel<F, LOGN, true, false>), cgrid, block, 0, A.stream, (char *)A.r0, (char *)A.r1, (const E *)part0, (const E *)part1,
+                               (const char *)A.a0, (const char *)A.a1, limbs, A.L, 2 * NP);
         return true;
     } else {
         return false;

@@ -676,16 +676,19 @@ ntt16_ct_multiply_kernel(typename F::E *__restrict__ c0, typename F::E *__restri
 // register order to a workspace (slot tid + r T); a second launch sums the partials of a (ciphertext, limb) and finishes as the one-launch
 // kernel does (paired inverse transform, addends, store).  Same arithmetic in the same order within a pair, and the sums of lazy values
 // are reduced exactly as the running accumulators are (pw_add), so the containers are bit-identical.
+// (grid.y = 2: the two digit sources of an external product -- c2 / c2b with the row tables kb, ka / kb_b, ka_b -- and 2 NP partials per limb polynomial)
 template <class F, int LOGN, bool COMPACT>
 __global__ void __launch_bounds__(NttCfg<LOGN>::T, 2)
-ntt_keyswitch2_part_kernel(typename F::E *__restrict__ part0, typename F::E *__restrict__ part1, const char *__restrict__ c2,
+ntt_keyswitch2_part_kernel(typename F::E *__restrict__ part0, typename F::E *__restrict__ part1, const char *__restrict__ c2, const char *__restrict__ c2b,
                            const typename F::E *__restrict__ kb, const typename F::E *__restrict__ ka,
+                           const typename F::E *__restrict__ kb_b, const typename F::E *__restrict__ ka_b,
                            const Limb<F> *__restrict__ limbs, uint32_t L, uint32_t K, uint32_t w) {
     using C = NttCfg<LOGN>;
     using E = typename F::E;
     __shared__ E lds[2 * C::LDS_ELEMS];
-    const uint32_t LK = L * K, NP = (LK + 1) / 2;
+    const uint32_t LK = L * K, NP = (LK + 1) / 2, comp = blockIdx.y, NPART = NP * gridDim.y;
     const uint32_t tid = threadIdx.x, pr = blockIdx.x % NP, p = blockIdx.x / NP, b = p / L, i = p % L;     // p = ciphertext * L + limb
+    if (comp) { c2 = c2b; kb = kb_b; ka = ka_b; }
     const Limb<F> P = limbs[i];
     const TableBuf C2(c2 + (size_t)b * L * (C::N * (COMPACT ? sizeof(E) : 32)));
     E acc0[32], acc1[32], d0[32], d1[32];
@@ -715,18 +718,17 @@ ntt_keyswitch2_part_kernel(typename F::E *__restrict__ part0, typename F::E *__r
         fwd_core<F, LOGN>(d0, lds, tid, P);
         mac_keys<F>(acc0, acc1, d0, kb, ka, ((size_t)jk * L + i) * C::N, tid, C::T, P);
     }
-    const size_t slot = ((size_t)p * NP + pr) * C::N;
+    const size_t slot = ((size_t)p * NPART + comp * NP + pr) * C::N;
     store_A_compact<F, LOGN>(part0 + slot, tid, acc0);    // register order: the combining launch reads slot tid + r T back into register r
     store_A_compact<F, LOGN>(part1 + slot, tid, acc1);
 }
-template <class F, int LOGN, bool ADD_COMPACT>
+template <class F, int LOGN, bool ADD_COMPACT, bool OUT_COMPACT = false>
 __global__ void __launch_bounds__(NttCfg<LOGN>::T, 2)
 ntt_keyswitch2_comb_kernel(char *c0, char *c1, const typename F::E *__restrict__ part0, const typename F::E *__restrict__ part1,
-                           const char *add0, const char *add1, const Limb<F> *__restrict__ limbs, uint32_t L, uint32_t K) {
+                           const char *add0, const char *add1, const Limb<F> *__restrict__ limbs, uint32_t L, uint32_t NP) {   // NP = partial pairs per limb polynomial
     using C = NttCfg<LOGN>;
     using E = typename F::E;
     __shared__ E lds[2 * C::LDS_ELEMS];
-    const uint32_t NP = (L * K + 1) / 2;
     const uint32_t tid = threadIdx.x, p = blockIdx.x, i = p % L;
     const Limb<F> P = limbs[i];
     E acc0[32], acc1[32], t0[32], t1[32];
@@ -738,7 +740,7 @@ ntt_keyswitch2_comb_kernel(char *c0, char *c1, const typename F::E *__restrict__
 #pragma unroll
         for (int r = 0; r < 32; r++) { acc0[r] = F::pw_add(acc0[r], t0[r], P.q, P.q2); acc1[r] = F::pw_add(acc1[r], t1[r], P.q, P.q2); }
     }
-    finish_pair<F, LOGN, ADD_COMPACT>(acc0, acc1, t0, t1, lds, tid, P, add0, add1, p, c0, c1);
+    finish_pair<F, LOGN, ADD_COMPACT, OUT_COMPACT>(acc0, acc1, t0, t1, lds, tid, P, add0, add1, p, c0, c1);
 }
 
 // Key switch of few ciphertexts on the 16-per-thread transforms (N <= 2^13, 4-byte residues): the digit-PAIR workgroups above run a paired 32-per-thread

@@ -810,7 +810,7 @@ def test_blind_rotate_step_matches_oracle(eng, oracle, n, spec, w, batch):
     assert np.array_equal(dA0.download(a0.shape), w0) and np.array_equal(dA1.download(a0.shape), w1)
 
 
-@pytest.mark.parametrize("n,spec,w,batch,steps", [(8192, ("bits", 30, 4), 16, 9, 3), (2048, ("bits", 30, 2), 30, 17, 2), (16384, ("bits", 30, 3), 16, 2, 1),
+@pytest.mark.parametrize("n,spec,w,batch,steps", [(8192, ("bits", 30, 4), 16, 9, 3), (2048, ("bits", 30, 2), 30, 17, 2), (16384, ("bits", 30, 3), 16, 2, 1), (16384, ("bits", 30, 2), 8, 3, 3),
                                                   (32768, ("bits", 30, 2), 16, 2, 2), (4096, ("bits", 40, 2), 20, 3, 3), (2048, ("bits", 60, 2), 32, 2, 2),
                                                   (256, ("bits", 250, 1), 64, 2, 2), (2048, ("bits", 64, 2), 32, 2, 3),
                                                   (16384, ("bits", 40, 2), 20, 2, 2), (16384, ("bits", 60, 1), 32, 1, 3)])      # three-array / split kernels

@@ -124,8 +124,9 @@ def test_small_batch_latency_kernel(resources):
         assert k["spill"] == 0 and k.get("scratch", 0) == 0 and k["vgprs"] <= 256 and k["occupancy"] >= 2 and k["lds"] == 32768, k
     for k in _all(kernels, "ntt16_ct_multiply_kernel", 1):       # the tensor product of few ciphertexts: four 16-entry arrays + 90 twiddles
         assert k["spill"] == 0 and k.get("scratch", 0) == 0 and k["vgprs"] <= 256 and k["occupancy"] >= 2 and k["lds"] == 32768, k
-    for name in ("ntt_keyswitch16_part_kernel", "ntt_keyswitch16_comb_kernel"):  # N <= 2^13: one workgroup per digit / per component on the 16-per-thread transforms
-        for k in _all(kernels, name, 2):
+    # N <= 2^13: one workgroup per digit / per component on the 16-per-thread transforms (key switch: compact or container c2 / addends; external product: compact output too)
+    for name, variants in (("ntt_keyswitch16_part_kernel", 2), ("ntt_keyswitch16_comb_kernel", 3)):
+        for k in _all(kernels, name, variants):
             assert k["spill"] == 0 and k.get("scratch", 0) == 0 and k["vgprs"] <= 256 and k["lds"] == 32768, (name, k)
     for name in ("ntt_keyswitch2_part_kernel", "ntt_keyswitch2_comb_kernel"):   # key switch of few ciphertexts: one workgroup per digit pair + combine
         for k in _all(kernels, name, 2):
