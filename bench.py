@@ -309,6 +309,28 @@ def extra_workloads():
     return out
 
 
+def extra_latency():
+    """One call on ONE polynomial / ciphertext / accumulator (the reference's API is one per call, include/ntt.cuh:78-84): microseconds per call of the fused polymul,
+    the one-call ciphertext multiply and a blind-rotation step, each a short child run at batch 1 (the library picks its few-ciphertext forms there)."""
+    import subprocess
+    specs = [("polymul N=8192 4x30-bit, batch 1", ["--op", "multiply", "--batch", "1"], 1),
+             ("ciphertext multiply (tensor + relin, w=16) N=8192 4x30-bit, batch 1", ["--op", "ctrelin", "--batch", "1"], 1),
+             ("blind-rotation step (external product, w=16) N=8192 4x30-bit, 1 accumulator", ["--op", "blindrotate", "--batch", "1"], None),
+             ("blind-rotation step N=16384 6x30-bit (configs[4] size), 1 accumulator", ["--op", "blindrotate", "--batch", "1", "--n", "16384", "--limbs", "6"], None)]
+    out = []
+    for name, extra, per_step in specs:
+        try:
+            args = [sys.executable, os.path.abspath(__file__), "--no-extras", "--no-cpu-baseline", "--steps", "200", "--warmup", "20"] + extra
+            res = subprocess.run(args, capture_output=True, text=True, timeout=300)
+            d = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][0])
+            # blindrotate: a step of the bench is a loop of several external products; value = external products per second at batch 1
+            us = d["ms_per_step"] * 1e3 if per_step else 1e6 / d["value"]
+            out.append({"workload": name, "us_per_call": us, "value": d["value"], "unit": d["unit"], "verified": d.get("verified")})
+        except Exception as e:
+            out.append({"workload": name, "error": str(e)[:200]})
+    return out
+
+
 def cpu_baseline(n, moduli, target_core_seconds=16.0):
     """CPU oracle (oracle/fhe_oracle.c, OpenMP over batch x limb) on a bounded sample of the same workload."""
     from oracle import pyoracle as orc
@@ -606,6 +628,7 @@ def main():
         out["extra_width_classes"] = extra_width_classes(pkg)
     if rank == 0 and world == 1 and not args.no_extras and not args.no_extra_workloads and args.op == "multiply" and args.shard == "batch":
         out["extra_workloads"] = extra_workloads()
+        out["extra_latency"] = extra_latency()
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.op == "multiply":
         out["cpu_baseline"] = cpu_baseline(n, moduli)
     if rank == 0:

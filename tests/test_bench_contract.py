@@ -51,6 +51,9 @@ def test_default_workload_line_has_every_contract_field():
     w = d["extra_workloads"]                  # the other BASELINE configurations, each a short child run
     assert len(w) == 6 and all("error" not in e and e["value"] > 0 and 0 < e["hbm_frac"] < 1 and e["int_mul_frac"] > 0 for e in w), w
     assert w[0]["unit"] == "ct-mul/s" and w[0]["verified"] is True and w[4]["unit"] == "extprod/s"
+    lat = d["extra_latency"]                  # one call on one polynomial / ciphertext / accumulator (the few-ciphertext forms)
+    assert len(lat) == 4 and all("error" not in e and 1.0 < e["us_per_call"] < 400.0 for e in lat), lat
+    assert lat[0]["us_per_call"] < 20.0 and lat[1]["us_per_call"] < 60.0 and lat[2]["us_per_call"] < 60.0, lat     # round 2: 24 / 97 / 103 us
     assert x[(250, 1)]["secondary"]["multiply_class_per_butterfly"] == 136 and x[(128, 1)]["secondary"]["multiply_class_per_butterfly"] == 136
     assert x[(250, 1)]["width_class"] == 4 and x[(40, 3)]["width_class"] == 3
 
